@@ -1,0 +1,156 @@
+/*
+ * m3d.h -- C ABI of libm3d_hip.so: the MI355X (gfx950) sparse-convolution engine behind
+ * Mosaic3D's SpUNet hot path (voxelize -> kernel maps -> sparse conv -> CLIP-text argmax).
+ *
+ * The reference (SLAM-Dunk-Prometheus/Segmentation, Python) reaches this arithmetic through the
+ * third-party wheels `spconv` and `torch_scatter` plus numpy on the host; each entry point below
+ * cites the reference call site it replaces (paths relative to /root/reference).
+ *
+ * Conventions
+ *   - every pointer named d_* is DEVICE memory owned by the caller (PyTorch tensors in practice);
+ *     the library never allocates or frees device memory and keeps no global mutable state except
+ *     a thread-local error string;
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it, nothing synchronises;
+ *   - data-dependent output sizes (number of voxels) are written to device memory; outputs are
+ *     sized by the caller for the worst case (one row per input row);
+ *   - return value: 0 on success, negative M3D_E* code on failure; m3d_last_error() gives text;
+ *   - scratch: each call that needs temporary memory takes (d_ws, ws_bytes); the matching
+ *     *_workspace_bytes() function returns the size required for given problem sizes.
+ */
+#ifndef M3D_H_
+#define M3D_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define M3D_OK 0
+#define M3D_EINVAL (-1)   /* bad argument (null pointer, unsupported size/shape) */
+#define M3D_ENOSPC (-2)   /* workspace too small */
+#define M3D_EHIP (-3)     /* a HIP runtime call or kernel launch failed */
+
+#define M3D_HASH_FNV 0
+#define M3D_HASH_RAVEL 1
+#define M3D_GRID_DIV 0    /* trunc(coord / grid_size): torch CPU kernel */
+#define M3D_GRID_RECIP 1  /* trunc(coord * (1/grid_size)): torch CUDA kernel for tensor/scalar */
+#define M3D_GRID_FLOOR 2  /* floor(coord / grid_size): GridSample (transform.py:753-754) */
+
+int m3d_version(void);
+const char* m3d_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Voxelize.  Replaces Point.sparsify + mean_pooling + fnv_hash_vec
+ * (mosaic3d/src/models/utils/structure.py:197-251, :34-66, :21-31) and offset2batch
+ * (mosaic3d/src/models/utils/misc.py:16-21).  With M3D_GRID_FLOOR and pad = 0 it also gives
+ * GridSample's hash / unique / inverse (mosaic3d/src/data/utils/transform.py:751-762).
+ *
+ *   d_coord   [n,3] f32     point coordinates
+ *   d_feat    [n,c] f32     point features (c >= 1)
+ *   d_offset  [b+1] i64     cumulative point counts with leading 0 (collate.py:96-102)
+ * outputs (caller allocates n rows each; the first n_voxels rows are valid)
+ *   d_voxel_coords [n,4] i32   (batch, x, y, z), ascending hash-key order
+ *   d_voxel_feats  [n,c] f32   per-voxel mean
+ *   d_v2p_map      [n]   i64   voxel row of every point
+ *   d_keys         [n]   u64   sorted unique hash keys (may be NULL)
+ *   d_grid_coord   [n,3] i32   per-point grid coordinate after the min shift (may be NULL)
+ *   d_meta         [16]  i64   [0]=n_voxels [1..3]=spatial_shape (max grid + pad)
+ *                              [4..6]=grid min before the shift [7..9]=grid max after the shift
+ */
+size_t m3d_voxelize_workspace_bytes(int64_t n, int c);
+int m3d_voxelize(const float* d_coord, const float* d_feat, const int64_t* d_offset, int64_t n,
+                 int c, int b, float grid_size, int pad, int hash_method, int grid_mode,
+                 int32_t* d_voxel_coords, float* d_voxel_feats, int64_t* d_v2p_map,
+                 uint64_t* d_keys, int32_t* d_grid_coord, int64_t* d_meta, void* d_ws,
+                 size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Submanifold kernel map (k = 3, dilation 1).  Replaces the indice-pair generation inside
+ * spconv.SubMConv3d.forward (call sites spconv_unet_v1m3_pdnorm.py:98-117, :205-212).
+ *   d_indices [n,4] i32 (batch, d0, d1, d2), rows distinct
+ *   d_pair    [27,n] i32  pair[k][j] = i with indices[i] == indices[j] + offset(k), else -1;
+ *                          k = (k0*3 + k1)*3 + k2, offset = (k0-1, k1-1, k2-1)
+ */
+size_t m3d_subm_rulebook_workspace_bytes(int64_t n);
+int m3d_subm_rulebook(const int32_t* d_indices, int64_t n, const int64_t spatial_shape[3],
+                      int32_t* d_pair, void* d_ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Strided kernel map (kernel 2, stride 2, padding 0).  Replaces the indice-pair generation of
+ * spconv.SparseConv3d (spconv_unet_v1m3_pdnorm.py:154-161); the same maps serve
+ * spconv.SparseInverseConv3d (:184-190) through pair_bwd.
+ *   d_out_indices [n,4] i32   output voxels, ascending row-major linear index over
+ *                             (batch, spatial_shape/2); first n_out rows valid
+ *   d_pair_fwd    [8,n]  i32  pair_fwd[k][o] = i or -1 (column stride n)
+ *   d_pair_bwd    [8,n]  i32  pair_bwd[k][i] = o or -1
+ *   d_n_out       [1]    i64
+ */
+size_t m3d_strided_rulebook_workspace_bytes(int64_t n);
+int m3d_strided_rulebook(const int32_t* d_indices, int64_t n, const int64_t spatial_shape[3],
+                         int32_t* d_out_indices, int32_t* d_pair_fwd, int32_t* d_pair_bwd,
+                         int64_t* d_n_out, void* d_ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Tile schedule of a kernel map: the order in which the convolution kernel walks output rows.
+ * Has no counterpart in the reference (spconv keeps this inside its implicit-GEMM planner).
+ *   d_pair [k,ld] i32  canonical kernel map (ld = column stride, n valid columns)
+ *   d_indices [n,4]    coordinates of the OUTPUT rows (used for the spatial sort), may be NULL
+ *   mode 0: identity order; 1: Morton order of d_indices; 2: group rows by their single active
+ *           kernel offset (inverse conv), Morton inside a group
+ * outputs, npad = m3d_schedule_npad(n):
+ *   d_nbr      [k,npad] i32  nbr[k][t] = pair[k][row(t)], -1 in the padding
+ *   d_out_row  [npad]   i32  row(t), -1 in the padding
+ *   d_tile_mask[npad/32] u32 bit k set iff any of the tile's 32 rows has a pair at offset k
+ */
+int64_t m3d_schedule_npad(int64_t n);
+size_t m3d_schedule_workspace_bytes(int64_t n);
+int m3d_build_schedule(const int32_t* d_pair, int k, int64_t ld, int64_t n,
+                       const int32_t* d_indices, int mode, int32_t* d_nbr, int32_t* d_out_row,
+                       uint32_t* d_tile_mask, void* d_ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Sparse convolution forward, fp32, implicit GEMM on v_mfma_f32_32x32x2_f32.
+ * Replaces the feature arithmetic of spconv.SubMConv3d / SparseConv3d / SparseInverseConv3d
+ * (call sites above) and Custom1x1Subm3d's torch.mm (structure.py:336-347), with the
+ * eval-mode PDBatchNorm affine, residual add and ReLU of BasicBlock.forward
+ * (spconv_unet_v1m3_pdnorm.py:121-140, :57-68) fused into the epilogue:
+ *
+ *   out[row(t)] = act( scale * sum_k W[k] . concat(in0, in1)[nbr[k][t]] + shift + residual[row(t)] )
+ *
+ *   d_in0 [*,c0], d_in1 [*,c1] (d_in1 may be NULL, c1 = 0): the two K-slabs of a concatenated
+ *        input (spconv_unet_v1m3_pdnorm.py:404) read without materialising the concat
+ *   d_weight [k,cout,c0+c1] f32: reference layout [Cout,k0,k1,k2,Cin] permuted to offset-major
+ *   d_nbr/d_out_row/d_tile_mask: from m3d_build_schedule; all three NULL = dense 1x1 (k = 1)
+ *   d_scale/d_shift [cout] may be NULL (1 / 0); d_residual [n_out_rows,cout] may be NULL
+ *   d_out [n_out_rows, ldo] (ldo >= cout, row stride in floats)
+ *   n = number of real output rows; npad = schedule length
+ */
+size_t m3d_conv_workspace_bytes(int64_t n, int cout, int k);
+int m3d_conv_fwd_f32(const float* d_in0, int c0, const float* d_in1, int c1,
+                     const float* d_weight, int k, int cout, const int32_t* d_nbr,
+                     const int32_t* d_out_row, const uint32_t* d_tile_mask, int64_t n,
+                     int64_t npad, const float* d_scale, const float* d_shift,
+                     const float* d_residual, int relu, float* d_out, int64_t ldo, void* d_ws,
+                     size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Open-vocabulary head.  Replaces clip_feat = features[v2p_map]
+ * (mosaic3d/src/models/lightning_modules/language_module.py:202-207),
+ * CLIPAlignmentEval.predict (mosaic3d/src/models/losses/clip_alignment_loss.py:138-147) and
+ * logits.max(1)[1] (language_module.py:328).  The row argmax is taken per voxel and gathered
+ * through v2p_map (argmax commutes with the row gather).
+ *   d_logits [n_vox, ldl] f32  per-voxel logits (columns >= n_classes are ignored)
+ *   d_voxel_label [n_vox] i32  first index of the row maximum
+ *   d_point_label [n_pts] i64  voxel_label[v2p_map[p]]
+ */
+int m3d_argmax_rows(const float* d_logits, int64_t n_vox, int n_classes, int64_t ldl,
+                    int32_t* d_voxel_label, void* stream);
+int m3d_gather_labels(const int32_t* d_voxel_label, const int64_t* d_v2p_map, int64_t n_pts,
+                      int64_t* d_point_label, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* M3D_H_ */

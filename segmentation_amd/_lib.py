@@ -1,0 +1,66 @@
+"""ctypes binding of libm3d_hip.so (the C ABI declared in include/m3d.h).
+
+The library is the product: if it is missing the import fails loudly; there is no CPU or
+PyTorch fallback for any operator."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libm3d_hip.so")
+
+_vp = ctypes.c_void_p
+_i64 = ctypes.c_int64
+_int = ctypes.c_int
+_sz = ctypes.c_size_t
+_f32 = ctypes.c_float
+
+# name -> (restype, argtypes); mirrors include/m3d.h one to one
+SIGNATURES = {
+    "m3d_version": (_int, []),
+    "m3d_last_error": (ctypes.c_char_p, []),
+    "m3d_voxelize_workspace_bytes": (_sz, [_i64, _int]),
+    "m3d_voxelize": (_int, [_vp, _vp, _vp, _i64, _int, _int, _f32, _int, _int, _int,
+                            _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "m3d_subm_rulebook_workspace_bytes": (_sz, [_i64]),
+    "m3d_subm_rulebook": (_int, [_vp, _i64, ctypes.POINTER(_i64), _vp, _vp, _sz, _vp]),
+    "m3d_strided_rulebook_workspace_bytes": (_sz, [_i64]),
+    "m3d_strided_rulebook": (_int, [_vp, _i64, ctypes.POINTER(_i64), _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "m3d_schedule_npad": (_i64, [_i64]),
+    "m3d_schedule_workspace_bytes": (_sz, [_i64]),
+    "m3d_build_schedule": (_int, [_vp, _int, _i64, _i64, _vp, _int, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "m3d_conv_workspace_bytes": (_sz, [_i64, _int, _int]),
+    "m3d_conv_fwd_f32": (_int, [_vp, _int, _vp, _int, _vp, _int, _int, _vp, _vp, _vp, _i64, _i64,
+                                _vp, _vp, _vp, _int, _vp, _i64, _vp, _sz, _vp]),
+    "m3d_argmax_rows": (_int, [_vp, _i64, _int, _i64, _vp, _vp]),
+    "m3d_gather_labels": (_int, [_vp, _vp, _i64, _vp, _vp]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library once and declare every entry point."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C segmentation_amd/csrc`.  segmentation_amd has no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here = header and library disagree
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+class M3DError(RuntimeError):
+    pass
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().m3d_last_error().decode("utf-8", "replace")
+        raise M3DError(f"{what} failed (code {rc}): {msg}")

@@ -1,0 +1,248 @@
+// Device primitives shared by the voxelizer and the kernel-map builders:
+//   * sort_pairs     stable LSD radix sort of (u64 key, u32 value), element count on the device
+//   * unique_sorted  np.unique(keys, return_inverse=True) + a representative index per key,
+//                    built on an open-addressing hash table in HBM + the radix sort
+// Everything runs on the caller's stream; no host synchronisation, no allocation.
+#include "common.h"
+
+#include <string.h>
+
+namespace m3d {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+const char* get_error() { return g_err; }
+
+// ------------------------------------------------------------------------------ radix sort
+constexpr int kWaveItems = 1024;   // elements ranked by one wave per pass
+constexpr int kSortBlock = 256;    // 4 waves per workgroup
+constexpr int kRounds = kWaveItems / 64;
+
+__global__ __launch_bounds__(kSortBlock) void radix_hist_kernel(
+    const uint64_t* __restrict__ keys, const int* __restrict__ d_count, int shift,
+    uint32_t* __restrict__ counts, int nchunks) {
+  __shared__ uint32_t h[kSortBlock / 64][256];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int chunk = blockIdx.x * (kSortBlock / 64) + wave;
+  for (int i = lane; i < 256; i += 64) h[wave][i] = 0;
+  __syncthreads();
+  if (chunk < nchunks) {
+    const int64_t m = *d_count;
+    const int64_t base = (int64_t)chunk * kWaveItems;
+    for (int r = 0; r < kRounds; ++r) {
+      int64_t i = base + r * 64 + lane;
+      if (i < m) atomicAdd(&h[wave][(keys[i] >> shift) & 255], 1u);
+    }
+  }
+  __syncthreads();
+  if (chunk < nchunks)
+    for (int i = lane; i < 256; i += 64) counts[(int64_t)i * nchunks + chunk] = h[wave][i];
+}
+
+// Exclusive prefix sum over `total` u32 entries, one workgroup of 1024 threads.
+__global__ __launch_bounds__(1024) void scan_exclusive_kernel(uint32_t* __restrict__ data,
+                                                               int64_t total) {
+  __shared__ uint32_t part[1024];
+  const int t = threadIdx.x;
+  const int64_t per = (total + 1023) / 1024;
+  const int64_t lo = t * per;
+  const int64_t hi = lo + per < total ? lo + per : total;
+  uint32_t s = 0;
+  for (int64_t i = lo; i < hi; ++i) s += data[i];
+  part[t] = s;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {
+    uint32_t v = t >= off ? part[t - off] : 0;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  uint32_t run = part[t] - s;  // exclusive prefix of this thread's segment
+  for (int64_t i = lo; i < hi; ++i) {
+    uint32_t v = data[i];
+    data[i] = run;
+    run += v;
+  }
+}
+
+__global__ __launch_bounds__(kSortBlock) void radix_scatter_kernel(
+    const uint64_t* __restrict__ kin, const uint32_t* __restrict__ vin,
+    uint64_t* __restrict__ kout, uint32_t* __restrict__ vout, const int* __restrict__ d_count,
+    int shift, const uint32_t* __restrict__ offsets, int nchunks) {
+  __shared__ uint32_t run_s[kSortBlock / 64][256];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int chunk = blockIdx.x * (kSortBlock / 64) + wave;
+  if (chunk < nchunks)
+    for (int i = lane; i < 256; i += 64) run_s[wave][i] = offsets[(int64_t)i * nchunks + chunk];
+  __syncthreads();
+  if (chunk >= nchunks) return;
+  volatile uint32_t* run = run_s[wave];
+  const int64_t m = *d_count;
+  const int64_t base = (int64_t)chunk * kWaveItems;
+  const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  for (int r = 0; r < kRounds; ++r) {
+    const int64_t i = base + r * 64 + lane;
+    const bool valid = i < m;
+    const uint64_t key = valid ? kin[i] : 0ull;
+    const uint32_t val = valid ? vin[i] : 0u;
+    const unsigned d = (unsigned)(key >> shift) & 255u;
+    uint64_t peers = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      const bool bit = (d >> b) & 1u;
+      const uint64_t bal = __ballot(bit);
+      peers &= bit ? bal : ~bal;
+    }
+    const int rank = __popcll(peers & lt);
+    const int cnt = __popcll(peers);
+    const uint32_t off = run[d];
+    if (valid) {
+      kout[off + rank] = key;
+      vout[off + rank] = val;
+      if (rank == 0) run[d] = off + cnt;
+    }
+  }
+}
+
+size_t sort_pairs_ws_bytes(int64_t nmax) {
+  int64_t nchunks = cdiv(nmax > 0 ? nmax : 1, kWaveItems);
+  return align_up((size_t)nchunks * 256 * sizeof(uint32_t));
+}
+
+int sort_pairs(uint64_t* d_keys, uint32_t* d_vals, uint64_t* d_keys_alt, uint32_t* d_vals_alt,
+               const int* d_count, int64_t nmax, int nbits, void* d_ws, size_t ws_bytes,
+               hipStream_t stream) {
+  if (nmax <= 0) return M3D_OK;
+  const int nchunks = (int)cdiv(nmax, kWaveItems);
+  if (ws_bytes < sort_pairs_ws_bytes(nmax) || d_ws == nullptr) {
+    set_error("sort_pairs: workspace too small");
+    return M3D_ENOSPC;
+  }
+  uint32_t* counts = static_cast<uint32_t*>(d_ws);
+  int passes = (nbits + 7) / 8;
+  if (passes < 2) passes = 2;
+  if (passes & 1) ++passes;  // an even number of passes leaves the result in (d_keys, d_vals)
+  if (passes > 8) passes = 8;
+  const int nblocks = (int)cdiv(nchunks, kSortBlock / 64);
+  uint64_t* ki = d_keys;
+  uint32_t* vi = d_vals;
+  uint64_t* ko = d_keys_alt;
+  uint32_t* vo = d_vals_alt;
+  for (int p = 0; p < passes; ++p) {
+    const int shift = 8 * p;
+    hipLaunchKernelGGL(radix_hist_kernel, dim3(nblocks), dim3(kSortBlock), 0, stream, ki, d_count,
+                       shift, counts, nchunks);
+    hipLaunchKernelGGL(scan_exclusive_kernel, dim3(1), dim3(1024), 0, stream, counts,
+                       (int64_t)nchunks * 256);
+    hipLaunchKernelGGL(radix_scatter_kernel, dim3(nblocks), dim3(kSortBlock), 0, stream, ki, vi,
+                       ko, vo, d_count, shift, counts, nchunks);
+    uint64_t* tk = ki; ki = ko; ko = tk;
+    uint32_t* tv = vi; vi = vo; vo = tv;
+  }
+  M3D_LAUNCH_CHECK();
+  return M3D_OK;
+}
+
+// ------------------------------------------------------------------------------ unique
+__global__ void unique_insert_kernel(const uint64_t* __restrict__ keys, int64_t n,
+                                     uint64_t* __restrict__ tkeys, int32_t* __restrict__ trep,
+                                     uint64_t mask, int32_t* __restrict__ pslot,
+                                     uint64_t* __restrict__ ukeys, uint32_t* __restrict__ uslot,
+                                     int* __restrict__ d_count) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t key = keys[i];
+  uint64_t s = mix64(key) & mask;
+  while (true) {
+    const uint64_t old = atomicCAS((unsigned long long*)&tkeys[s], (unsigned long long)kEmptyKey,
+                                   (unsigned long long)key);
+    if (old == kEmptyKey) {
+      trep[s] = (int32_t)i;
+      const int pos = atomicAdd(d_count, 1);
+      ukeys[pos] = key;
+      uslot[pos] = (uint32_t)s;
+      pslot[i] = (int32_t)s;
+      return;
+    }
+    if (old == key) {
+      pslot[i] = (int32_t)s;
+      return;
+    }
+    s = (s + 1) & mask;
+  }
+}
+
+__global__ void unique_rank_kernel(const uint32_t* __restrict__ uslot, const int* __restrict__ d_count,
+                                   int32_t* __restrict__ trep, int32_t* __restrict__ rep_out) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= *d_count) return;
+  const uint32_t s = uslot[r];
+  rep_out[r] = trep[s];
+  trep[s] = (int32_t)r;  // the slot now holds the rank of its key
+}
+
+__global__ void unique_inverse_kernel(const int32_t* __restrict__ pslot, const int32_t* __restrict__ trank,
+                                      int64_t n, int32_t* __restrict__ inverse) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) inverse[i] = trank[pslot[i]];
+}
+
+static inline uint64_t table_capacity(int64_t n) { return next_pow2((uint64_t)(n > 0 ? n : 1) * 2); }
+
+size_t unique_ws_bytes(int64_t n) {
+  if (n <= 0) n = 1;
+  const uint64_t cap = table_capacity(n);
+  size_t b = 0;
+  b += align_up(cap * sizeof(uint64_t));   // table keys
+  b += align_up(cap * sizeof(int32_t));    // table rep / rank
+  b += align_up(n * sizeof(int32_t));      // pslot
+  b += align_up(n * sizeof(uint64_t));     // alt keys
+  b += 2 * align_up(n * sizeof(uint32_t)); // slot values + alt
+  b += sort_pairs_ws_bytes(n);
+  return b;
+}
+
+int unique_sorted(const uint64_t* d_keys, int64_t n, uint64_t* d_ukeys, int32_t* d_rep,
+                  int32_t* d_inverse, int* d_count, void* d_ws, size_t ws_bytes,
+                  hipStream_t stream) {
+  M3D_HIP(hipMemsetAsync(d_count, 0, sizeof(int), stream));
+  if (n <= 0) return M3D_OK;
+  const uint64_t cap = table_capacity(n);
+  Arena a(d_ws, ws_bytes);
+  uint64_t* tkeys = a.take<uint64_t>(cap);
+  int32_t* trep = a.take<int32_t>(cap);
+  int32_t* pslot = a.take<int32_t>(n);
+  uint64_t* kalt = a.take<uint64_t>(n);
+  uint32_t* uslot = a.take<uint32_t>(n);
+  uint32_t* valt = a.take<uint32_t>(n);
+  const size_t sort_bytes = sort_pairs_ws_bytes(n);
+  char* sort_ws = a.take<char>(sort_bytes);
+  if (!a.ok) {
+    set_error("unique_sorted: workspace too small (%zu needed, %zu given)", a.off, ws_bytes);
+    return M3D_ENOSPC;
+  }
+  M3D_HIP(hipMemsetAsync(tkeys, 0xFF, cap * sizeof(uint64_t), stream));
+  const int bs = 256;
+  hipLaunchKernelGGL(unique_insert_kernel, dim3((unsigned)cdiv(n, bs)), dim3(bs), 0, stream, d_keys,
+                     n, tkeys, trep, cap - 1, pslot, d_ukeys, uslot, d_count);
+  int rc = sort_pairs(d_ukeys, uslot, kalt, valt, d_count, n, 64, sort_ws, sort_bytes, stream);
+  if (rc != M3D_OK) return rc;
+  hipLaunchKernelGGL(unique_rank_kernel, dim3((unsigned)cdiv(n, bs)), dim3(bs), 0, stream, uslot,
+                     d_count, trep, d_rep);
+  hipLaunchKernelGGL(unique_inverse_kernel, dim3((unsigned)cdiv(n, bs)), dim3(bs), 0, stream, pslot,
+                     trep, n, d_inverse);
+  M3D_LAUNCH_CHECK();
+  return M3D_OK;
+}
+
+}  // namespace m3d
+
+extern "C" int m3d_version(void) { return 1; }
+extern "C" const char* m3d_last_error(void) { return m3d::get_error(); }

@@ -1,0 +1,319 @@
+// Kernel-map ("rulebook") construction for submanifold (k=3) and strided (k=2, s=2) sparse
+// convolutions, plus the tile schedule the convolution kernel walks.
+//
+// Coordinates are linearised to a 64-bit row-major index over (batch, spatial_shape) -- never a
+// 32-bit offset -- and looked up in an open-addressing hash table in HBM (load factor <= 0.5,
+// linear probing, 64-bit CAS insert).  The table for a 250 k-voxel level is 6 MB and stays in L2.
+#include "common.h"
+
+#include <limits.h>
+
+namespace m3d {
+
+constexpr uint64_t kDropKey = 0xFFFFFFFFFFFFFFFEull;  // sorts after every real key
+
+struct Shape3 {
+  int64_t s[3];
+};
+
+__device__ inline uint64_t lin_key(int b, int x, int y, int z, const Shape3& sh) {
+  return (((uint64_t)b * (uint64_t)sh.s[0] + (uint64_t)x) * (uint64_t)sh.s[1] + (uint64_t)y) *
+             (uint64_t)sh.s[2] + (uint64_t)z;
+}
+
+__global__ void set_int_kernel(int* p, int v) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) *p = v;
+}
+
+// ------------------------------------------------------------------------------ SubM k3
+__global__ void subm_insert_kernel(const int4* __restrict__ idx, int64_t n, Shape3 sh,
+                                   uint64_t* __restrict__ tkeys, int32_t* __restrict__ tvals,
+                                   uint64_t mask) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const int4 c = idx[j];
+  const uint64_t key = lin_key(c.x, c.y, c.z, c.w, sh);
+  uint64_t s = mix64(key) & mask;
+  while (true) {
+    const uint64_t old = atomicCAS((unsigned long long*)&tkeys[s], (unsigned long long)kEmptyKey,
+                                   (unsigned long long)key);
+    if (old == kEmptyKey) {
+      tvals[s] = (int32_t)j;
+      return;
+    }
+    if (old == key) return;  // duplicate row: the first inserter keeps the slot
+    s = (s + 1) & mask;
+  }
+}
+
+__global__ __launch_bounds__(256) void subm_probe_kernel(const int4* __restrict__ idx, int64_t n,
+                                                         Shape3 sh, HashTable tab,
+                                                         int32_t* __restrict__ pair) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int k = blockIdx.y;
+  if (j >= n) return;
+  const int4 c = idx[j];
+  const int x = c.y + (k / 9) - 1, y = c.z + ((k / 3) % 3) - 1, z = c.w + (k % 3) - 1;
+  int32_t r = -1;
+  if (k == 13) {
+    r = (int32_t)j;
+  } else if (x >= 0 && y >= 0 && z >= 0 && x < sh.s[0] && y < sh.s[1] && z < sh.s[2]) {
+    r = table_find(tab, lin_key(c.x, x, y, z, sh));
+  }
+  pair[(int64_t)k * n + j] = r;
+}
+
+// ------------------------------------------------------------------------------ strided k2 s2
+__global__ void strided_key_kernel(const int4* __restrict__ idx, int64_t n, Shape3 out_sh,
+                                   uint64_t* __restrict__ keys) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int4 c = idx[i];
+  const int x = c.y >> 1, y = c.z >> 1, z = c.w >> 1;
+  const bool ok = x < out_sh.s[0] && y < out_sh.s[1] && z < out_sh.s[2];
+  keys[i] = ok ? lin_key(c.x, x, y, z, out_sh) : kDropKey;
+}
+
+__global__ void strided_count_kernel(const uint64_t* __restrict__ ukeys, const int* __restrict__ d_count,
+                                     int* __restrict__ d_nout, int64_t* __restrict__ n_out64) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  int m = *d_count;
+  if (m > 0 && ukeys[m - 1] == kDropKey) --m;
+  *d_nout = m;
+  *n_out64 = m;
+}
+
+__global__ void strided_pair_kernel(const int4* __restrict__ idx, const int32_t* __restrict__ inverse,
+                                    int64_t n, const int* __restrict__ d_nout,
+                                    int32_t* __restrict__ pair_fwd, int32_t* __restrict__ pair_bwd) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int o = inverse[i];
+  if (o >= *d_nout) return;
+  const int4 c = idx[i];
+  const int k = ((c.y & 1) * 2 + (c.z & 1)) * 2 + (c.w & 1);
+  pair_fwd[(int64_t)k * n + o] = (int32_t)i;
+  pair_bwd[(int64_t)k * n + i] = o;
+}
+
+__global__ void strided_outidx_kernel(const uint64_t* __restrict__ ukeys, const int* __restrict__ d_nout,
+                                      Shape3 out_sh, int4* __restrict__ out_idx) {
+  const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= *d_nout) return;
+  uint64_t r = ukeys[o];
+  const int z = (int)(r % (uint64_t)out_sh.s[2]); r /= (uint64_t)out_sh.s[2];
+  const int y = (int)(r % (uint64_t)out_sh.s[1]); r /= (uint64_t)out_sh.s[1];
+  const int x = (int)(r % (uint64_t)out_sh.s[0]); r /= (uint64_t)out_sh.s[0];
+  out_idx[o] = make_int4((int)r, x, y, z);
+}
+
+// ------------------------------------------------------------------------------ schedule
+__device__ inline uint64_t spread3(uint64_t v) {  // 16 bits -> every third bit
+  v &= 0xFFFFull;
+  v = (v | (v << 32)) & 0x1F00000000FFFFull;
+  v = (v | (v << 16)) & 0x1F0000FF0000FFull;
+  v = (v | (v << 8)) & 0x100F00F00F00F00Full;
+  v = (v | (v << 4)) & 0x10C30C30C30C30C3ull;
+  v = (v | (v << 2)) & 0x1249249249249249ull;
+  return v;
+}
+
+__global__ void sched_key_kernel(const int32_t* __restrict__ pair, int kvol, int64_t ld, int64_t n,
+                                 const int4* __restrict__ idx, int mode, uint64_t* __restrict__ keys,
+                                 uint32_t* __restrict__ vals) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  uint64_t key = 0;
+  if (idx) {
+    const int4 c = idx[t];
+    key = ((uint64_t)(c.x & 0xFFF) << 48) | (spread3((uint64_t)c.y) << 2) |
+          (spread3((uint64_t)c.z) << 1) | spread3((uint64_t)c.w);
+  } else {
+    key = (uint64_t)t;
+  }
+  if (mode == 2) {
+    int kk = kvol;  // rows without any pair go last
+    for (int k = 0; k < kvol; ++k)
+      if (pair[(int64_t)k * ld + t] >= 0) { kk = k; break; }
+    key |= (uint64_t)(kk & 0xF) << 60;
+  }
+  keys[t] = key;
+  vals[t] = (uint32_t)t;
+}
+
+__global__ __launch_bounds__(256) void sched_gather_kernel(const int32_t* __restrict__ pair, int64_t ld,
+                                                           int64_t n, int64_t npad,
+                                                           const uint32_t* __restrict__ order,
+                                                           int32_t* __restrict__ nbr,
+                                                           int32_t* __restrict__ out_row) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int k = blockIdx.y;
+  if (t >= npad) return;
+  const int32_t row = t < n ? (order ? (int32_t)order[t] : (int32_t)t) : -1;
+  if (k == 0) out_row[t] = row;
+  nbr[(int64_t)k * npad + t] = row >= 0 ? pair[(int64_t)k * ld + row] : -1;
+}
+
+// One wave per 64 schedule rows = two 32-row tiles.
+__global__ __launch_bounds__(256) void sched_mask_kernel(const int32_t* __restrict__ nbr, int kvol,
+                                                         int64_t npad, uint32_t* __restrict__ tile_mask) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t base = ((int64_t)blockIdx.x * 4 + wave) * 64;
+  if (base >= npad) return;
+  uint32_t lo = 0, hi = 0;
+  for (int k = 0; k < kvol; ++k) {
+    const bool v = nbr[(int64_t)k * npad + base + lane] >= 0;
+    const uint64_t bal = __ballot(v);
+    if (bal & 0xFFFFFFFFull) lo |= 1u << k;
+    if (bal >> 32) hi |= 1u << k;
+  }
+  if (lane == 0) {
+    tile_mask[base / 32] = lo;
+    tile_mask[base / 32 + 1] = hi;
+  }
+}
+
+static inline uint64_t table_cap(int64_t n) { return next_pow2((uint64_t)(n > 0 ? n : 1) * 2); }
+
+}  // namespace m3d
+
+using namespace m3d;
+
+static int check_shape(const int64_t s[3], const char* who) {
+  for (int a = 0; a < 3; ++a)
+    if (s[a] <= 0 || s[a] > (int64_t)INT_MAX) {
+      set_error("%s: spatial_shape[%d]=%lld out of range", who, a, (long long)s[a]);
+      return M3D_EINVAL;
+    }
+  return M3D_OK;
+}
+
+extern "C" size_t m3d_subm_rulebook_workspace_bytes(int64_t n) {
+  const uint64_t cap = table_cap(n);
+  return align_up(cap * sizeof(uint64_t)) + align_up(cap * sizeof(int32_t));
+}
+
+extern "C" int m3d_subm_rulebook(const int32_t* d_indices, int64_t n, const int64_t spatial_shape[3],
+                                 int32_t* d_pair, void* d_ws, size_t ws_bytes, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  M3D_CHECK_ARG(n >= 0 && n < (int64_t)INT_MAX, "m3d_subm_rulebook: n out of range");
+  if (n == 0) return M3D_OK;
+  M3D_CHECK_ARG(d_indices && d_pair && spatial_shape, "m3d_subm_rulebook: null pointer");
+  if (int rc = check_shape(spatial_shape, "m3d_subm_rulebook")) return rc;
+  const uint64_t cap = table_cap(n);
+  Arena a(d_ws, ws_bytes);
+  uint64_t* tkeys = a.take<uint64_t>(cap);
+  int32_t* tvals = a.take<int32_t>(cap);
+  if (!a.ok) {
+    set_error("m3d_subm_rulebook: workspace too small (%zu given, %zu needed)", ws_bytes, a.off);
+    return M3D_ENOSPC;
+  }
+  Shape3 sh{{spatial_shape[0], spatial_shape[1], spatial_shape[2]}};
+  M3D_HIP(hipMemsetAsync(tkeys, 0xFF, cap * sizeof(uint64_t), stream));
+  const int bs = 256;
+  const unsigned gb = (unsigned)cdiv(n, bs);
+  const int4* idx = reinterpret_cast<const int4*>(d_indices);
+  hipLaunchKernelGGL(subm_insert_kernel, dim3(gb), dim3(bs), 0, stream, idx, n, sh, tkeys, tvals,
+                     cap - 1);
+  HashTable tab{tkeys, tvals, cap - 1};
+  hipLaunchKernelGGL(subm_probe_kernel, dim3(gb, 27), dim3(bs), 0, stream, idx, n, sh, tab, d_pair);
+  M3D_LAUNCH_CHECK();
+  return M3D_OK;
+}
+
+extern "C" size_t m3d_strided_rulebook_workspace_bytes(int64_t n) {
+  if (n <= 0) n = 1;
+  return align_up(n * sizeof(uint64_t)) * 2 + align_up(n * sizeof(int32_t)) * 2 +
+         align_up(64 * sizeof(int)) * 2 + align_up(unique_ws_bytes(n));
+}
+
+extern "C" int m3d_strided_rulebook(const int32_t* d_indices, int64_t n, const int64_t spatial_shape[3],
+                                    int32_t* d_out_indices, int32_t* d_pair_fwd, int32_t* d_pair_bwd,
+                                    int64_t* d_n_out, void* d_ws, size_t ws_bytes, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  M3D_CHECK_ARG(n > 0 && n < (int64_t)INT_MAX, "m3d_strided_rulebook: n out of range");
+  M3D_CHECK_ARG(d_indices && d_out_indices && d_pair_fwd && d_pair_bwd && d_n_out && spatial_shape,
+                "m3d_strided_rulebook: null pointer");
+  if (int rc = check_shape(spatial_shape, "m3d_strided_rulebook")) return rc;
+  Shape3 osh{{spatial_shape[0] / 2, spatial_shape[1] / 2, spatial_shape[2] / 2}};
+  M3D_CHECK_ARG(osh.s[0] > 0 && osh.s[1] > 0 && osh.s[2] > 0,
+                "m3d_strided_rulebook: spatial shape too small for a stride-2 convolution");
+  Arena a(d_ws, ws_bytes);
+  uint64_t* keys = a.take<uint64_t>(n);
+  uint64_t* ukeys = a.take<uint64_t>(n);
+  int32_t* rep = a.take<int32_t>(n);
+  int32_t* inverse = a.take<int32_t>(n);
+  int* count = a.take<int>(64);
+  int* nout = a.take<int>(64);
+  const size_t ub = unique_ws_bytes(n);
+  char* uws = a.take<char>(ub);
+  if (!a.ok) {
+    set_error("m3d_strided_rulebook: workspace too small (%zu given, %zu needed)", ws_bytes, a.off);
+    return M3D_ENOSPC;
+  }
+  const int bs = 256;
+  const unsigned gb = (unsigned)cdiv(n, bs);
+  const int4* idx = reinterpret_cast<const int4*>(d_indices);
+  hipLaunchKernelGGL(strided_key_kernel, dim3(gb), dim3(bs), 0, stream, idx, n, osh, keys);
+  M3D_LAUNCH_CHECK();
+  int rc = unique_sorted(keys, n, ukeys, rep, inverse, count, uws, ub, stream);
+  if (rc != M3D_OK) return rc;
+  hipLaunchKernelGGL(strided_count_kernel, dim3(1), dim3(64), 0, stream, ukeys, count, nout, d_n_out);
+  M3D_HIP(hipMemsetAsync(d_pair_fwd, 0xFF, (size_t)8 * n * sizeof(int32_t), stream));
+  M3D_HIP(hipMemsetAsync(d_pair_bwd, 0xFF, (size_t)8 * n * sizeof(int32_t), stream));
+  hipLaunchKernelGGL(strided_pair_kernel, dim3(gb), dim3(bs), 0, stream, idx, inverse, n, nout,
+                     d_pair_fwd, d_pair_bwd);
+  hipLaunchKernelGGL(strided_outidx_kernel, dim3(gb), dim3(bs), 0, stream, ukeys, nout, osh,
+                     reinterpret_cast<int4*>(d_out_indices));
+  M3D_LAUNCH_CHECK();
+  return M3D_OK;
+}
+
+extern "C" int64_t m3d_schedule_npad(int64_t n) { return cdiv(n > 0 ? n : 1, 128) * 128; }
+
+extern "C" size_t m3d_schedule_workspace_bytes(int64_t n) {
+  if (n <= 0) n = 1;
+  return align_up(n * sizeof(uint64_t)) * 2 + align_up(n * sizeof(uint32_t)) * 2 +
+         align_up(64 * sizeof(int)) + align_up(sort_pairs_ws_bytes(n));
+}
+
+extern "C" int m3d_build_schedule(const int32_t* d_pair, int k, int64_t ld, int64_t n,
+                                  const int32_t* d_indices, int mode, int32_t* d_nbr,
+                                  int32_t* d_out_row, uint32_t* d_tile_mask, void* d_ws,
+                                  size_t ws_bytes, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  M3D_CHECK_ARG(n > 0 && n < (int64_t)INT_MAX, "m3d_build_schedule: n out of range");
+  M3D_CHECK_ARG(k >= 1 && k <= 27 && ld >= n, "m3d_build_schedule: k=%d ld=%lld", k, (long long)ld);
+  M3D_CHECK_ARG(d_pair && d_nbr && d_out_row && d_tile_mask, "m3d_build_schedule: null pointer");
+  M3D_CHECK_ARG(mode >= 0 && mode <= 2, "m3d_build_schedule: unknown mode %d", mode);
+  const int64_t npad = m3d_schedule_npad(n);
+  const int bs = 256;
+  const uint32_t* order = nullptr;
+  if (mode != 0) {
+    Arena a(d_ws, ws_bytes);
+    uint64_t* keys = a.take<uint64_t>(n);
+    uint64_t* kalt = a.take<uint64_t>(n);
+    uint32_t* vals = a.take<uint32_t>(n);
+    uint32_t* valt = a.take<uint32_t>(n);
+    int* count = a.take<int>(64);
+    const size_t sb = sort_pairs_ws_bytes(n);
+    char* sws = a.take<char>(sb);
+    if (!a.ok) {
+      set_error("m3d_build_schedule: workspace too small (%zu given, %zu needed)", ws_bytes, a.off);
+      return M3D_ENOSPC;
+    }
+    hipLaunchKernelGGL(set_int_kernel, dim3(1), dim3(64), 0, stream, count, (int)n);
+    hipLaunchKernelGGL(sched_key_kernel, dim3((unsigned)cdiv(n, bs)), dim3(bs), 0, stream, d_pair, k, ld,
+                       n, reinterpret_cast<const int4*>(d_indices), mode, keys, vals);
+    M3D_LAUNCH_CHECK();
+    int rc = sort_pairs(keys, vals, kalt, valt, count, n, 64, sws, sb, stream);
+    if (rc != M3D_OK) return rc;
+    order = vals;
+  }
+  hipLaunchKernelGGL(sched_gather_kernel, dim3((unsigned)cdiv(npad, bs), k), dim3(bs), 0, stream, d_pair,
+                     ld, n, npad, order, d_nbr, d_out_row);
+  hipLaunchKernelGGL(sched_mask_kernel, dim3((unsigned)cdiv(npad, 256)), dim3(256), 0, stream, d_nbr, k,
+                     npad, d_tile_mask);
+  M3D_LAUNCH_CHECK();
+  return M3D_OK;
+}

@@ -1,0 +1,240 @@
+// Voxelizer: points -> grid coordinates -> 64-bit hash keys -> unique voxels in ascending key
+// order, per-voxel mean features and the voxel row of every point.
+//
+// Semantics follow the reference's Point.sparsify / mean_pooling / fnv_hash_vec
+// (mosaic3d/src/models/utils/structure.py:197-251, :34-66, :21-31): trunc-toward-zero grid rule,
+// minimum taken over the whole batch, FNV64-1A over the (batch, x, y, z) columns, voxel order =
+// ascending key.  Data layout in HBM: structure-of-rows exactly as the reference tensors
+// ([n,3] f32 coords, [n,c] f32 feats, [n,4] i32 voxel coords), so the outputs are torch views.
+#include "common.h"
+
+#include <limits.h>
+
+namespace m3d {
+
+constexpr uint64_t kFnvOffset = 14695981039346656037ull;
+constexpr uint64_t kFnvPrime = 1099511628211ull;
+
+__device__ inline int grid_of(float x, float gs, float inv_gs, int mode) {
+  float q;
+  if (mode == M3D_GRID_RECIP) q = x * inv_gs;
+  else q = __fdiv_rn(x, gs);
+  if (mode == M3D_GRID_FLOOR) q = floorf(q);
+  return (int)q;  // truncation toward zero
+}
+
+__device__ inline int batch_of(const int64_t* __restrict__ offset, int b, int64_t i) {
+  // largest j in [0, b) with offset[j] <= i
+  int lo = 0, hi = b - 1;
+  while (lo < hi) {
+    int mid = (lo + hi + 1) >> 1;
+    if (offset[mid] <= i) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}
+
+// mm[0..2] = min grid, mm[3..5] = max grid, mm[6] = min batch, mm[7] = max batch
+__global__ void vox_init_kernel(int* mm) {
+  const int t = threadIdx.x;
+  if (t < 3) mm[t] = INT_MAX;
+  else if (t < 6) mm[t] = INT_MIN;
+  else if (t == 6) mm[t] = INT_MAX;
+  else if (t == 7) mm[t] = INT_MIN;
+}
+
+__global__ __launch_bounds__(256) void vox_minmax_kernel(const float* __restrict__ coord,
+                                                         const int64_t* __restrict__ offset, int64_t n,
+                                                         int b, float gs, float inv_gs, int mode,
+                                                         int* __restrict__ mm) {
+  int lo[3] = {INT_MAX, INT_MAX, INT_MAX}, hi[3] = {INT_MIN, INT_MIN, INT_MIN};
+  int blo = INT_MAX, bhi = INT_MIN;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      int g = grid_of(coord[i * 3 + a], gs, inv_gs, mode);
+      lo[a] = min(lo[a], g);
+      hi[a] = max(hi[a], g);
+    }
+    int bi = batch_of(offset, b, i);
+    blo = min(blo, bi);
+    bhi = max(bhi, bi);
+  }
+#pragma unroll
+  for (int s = 32; s > 0; s >>= 1) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      lo[a] = min(lo[a], __shfl_xor(lo[a], s));
+      hi[a] = max(hi[a], __shfl_xor(hi[a], s));
+    }
+    blo = min(blo, __shfl_xor(blo, s));
+    bhi = max(bhi, __shfl_xor(bhi, s));
+  }
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      atomicMin(&mm[a], lo[a]);
+      atomicMax(&mm[3 + a], hi[a]);
+    }
+    atomicMin(&mm[6], blo);
+    atomicMax(&mm[7], bhi);
+  }
+}
+
+__global__ __launch_bounds__(256) void vox_key_kernel(const float* __restrict__ coord,
+                                                      const int64_t* __restrict__ offset, int64_t n,
+                                                      int b, float gs, float inv_gs, int mode,
+                                                      int hash_method, const int* __restrict__ mm,
+                                                      uint64_t* __restrict__ keys,
+                                                      int4* __restrict__ bc,
+                                                      int32_t* __restrict__ grid_out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int g[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) g[a] = grid_of(coord[i * 3 + a], gs, inv_gs, mode) - mm[a];
+  const int bi = batch_of(offset, b, i);
+  bc[i] = make_int4(bi, g[0], g[1], g[2]);
+  if (grid_out) {
+    grid_out[i * 3 + 0] = g[0];
+    grid_out[i * 3 + 1] = g[1];
+    grid_out[i * 3 + 2] = g[2];
+  }
+  uint64_t h;
+  if (hash_method == M3D_HASH_FNV) {
+    h = kFnvOffset;
+    h *= kFnvPrime; h ^= (uint64_t)(int64_t)bi;
+    h *= kFnvPrime; h ^= (uint64_t)(int64_t)g[0];
+    h *= kFnvPrime; h ^= (uint64_t)(int64_t)g[1];
+    h *= kFnvPrime; h ^= (uint64_t)(int64_t)g[2];
+  } else {
+    // row-major linear index of (b - bmin, x, y, z) over shape (max - min + 1)
+    const uint64_t s1 = (uint64_t)(mm[3] - mm[0] + 1), s2 = (uint64_t)(mm[4] - mm[1] + 1),
+                   s3 = (uint64_t)(mm[5] - mm[2] + 1);
+    h = (((uint64_t)(bi - mm[6]) * s1 + (uint64_t)g[0]) * s2 + (uint64_t)g[1]) * s3 + (uint64_t)g[2];
+  }
+  keys[i] = h;
+}
+
+__global__ void vox_coords_kernel(const int32_t* __restrict__ rep, const int4* __restrict__ bc,
+                                  const int* __restrict__ d_count, int4* __restrict__ voxel_coords) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < *d_count) voxel_coords[r] = bc[rep[r]];
+}
+
+__global__ void vox_accum_kernel(const float* __restrict__ feat, const int32_t* __restrict__ inverse,
+                                 int64_t n, int c, double* __restrict__ sums, int32_t* __restrict__ cnt,
+                                 int64_t* __restrict__ v2p) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int r = inverse[i];
+  v2p[i] = r;
+  atomicAdd(&cnt[r], 1);
+  for (int j = 0; j < c; ++j) atomicAdd(&sums[(int64_t)r * c + j], (double)feat[i * c + j]);
+}
+
+__global__ void vox_mean_kernel(const double* __restrict__ sums, const int32_t* __restrict__ cnt,
+                                const int* __restrict__ d_count, int c, float* __restrict__ voxel_feats) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t total = (int64_t)(*d_count) * c;
+  if (t < total) voxel_feats[t] = (float)(sums[t] / (double)cnt[t / c]);
+}
+
+__global__ void vox_meta_kernel(const int* __restrict__ mm, const int* __restrict__ d_count, int pad,
+                                int64_t* __restrict__ meta) {
+  if (threadIdx.x != 0) return;
+  meta[0] = *d_count;
+  for (int a = 0; a < 3; ++a) {
+    meta[1 + a] = (int64_t)(mm[3 + a] - mm[a]) + pad;
+    meta[4 + a] = mm[a];
+    meta[7 + a] = mm[3 + a] - mm[a];
+  }
+  meta[10] = mm[6];
+  meta[11] = mm[7];
+}
+
+struct VoxWs {
+  uint64_t* keys;
+  int4* bc;
+  int32_t* rep;
+  int32_t* inverse;
+  double* sums;
+  int32_t* cnt;
+  uint64_t* ukeys;
+  int* count;
+  int* mm;
+  char* uniq;
+  size_t uniq_bytes;
+};
+
+static size_t vox_layout(int64_t n, int c, void* ws, size_t bytes, VoxWs* out) {
+  if (n <= 0) n = 1;
+  Arena a(ws, bytes);
+  VoxWs w;
+  w.keys = a.take<uint64_t>(n);
+  w.bc = a.take<int4>(n);
+  w.rep = a.take<int32_t>(n);
+  w.inverse = a.take<int32_t>(n);
+  w.sums = a.take<double>((size_t)n * c);
+  w.cnt = a.take<int32_t>(n);
+  w.ukeys = a.take<uint64_t>(n);
+  w.count = a.take<int>(64);
+  w.mm = a.take<int>(64);
+  w.uniq_bytes = unique_ws_bytes(n);
+  w.uniq = a.take<char>(w.uniq_bytes);
+  if (out) *out = w;
+  return a.off;  // bytes required (valid pointers only if this fits in `bytes`)
+}
+
+}  // namespace m3d
+
+using namespace m3d;
+
+extern "C" size_t m3d_voxelize_workspace_bytes(int64_t n, int c) {
+  return vox_layout(n, c < 1 ? 1 : c, nullptr, 0, nullptr);
+}
+
+extern "C" int m3d_voxelize(const float* d_coord, const float* d_feat, const int64_t* d_offset,
+                            int64_t n, int c, int b, float grid_size, int pad, int hash_method,
+                            int grid_mode, int32_t* d_voxel_coords, float* d_voxel_feats,
+                            int64_t* d_v2p_map, uint64_t* d_keys, int32_t* d_grid_coord,
+                            int64_t* d_meta, void* d_ws, size_t ws_bytes, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  M3D_CHECK_ARG(n > 0 && n < (int64_t)INT_MAX, "m3d_voxelize: n=%lld out of range", (long long)n);
+  M3D_CHECK_ARG(c >= 1 && b >= 1, "m3d_voxelize: c=%d b=%d", c, b);
+  M3D_CHECK_ARG(d_coord && d_feat && d_offset && d_voxel_coords && d_voxel_feats && d_v2p_map && d_meta,
+                "m3d_voxelize: null pointer");
+  M3D_CHECK_ARG(grid_size > 0.f, "m3d_voxelize: grid_size must be positive");
+  M3D_CHECK_ARG(hash_method == M3D_HASH_FNV || hash_method == M3D_HASH_RAVEL,
+                "m3d_voxelize: unknown hash method %d", hash_method);
+  M3D_CHECK_ARG(grid_mode >= 0 && grid_mode <= 2, "m3d_voxelize: unknown grid mode %d", grid_mode);
+  VoxWs w;
+  size_t need = vox_layout(n, c, d_ws, ws_bytes, &w);
+  if (need > ws_bytes || d_ws == nullptr) {
+    set_error("m3d_voxelize: workspace too small (%zu given, %zu needed)", ws_bytes, need);
+    return M3D_ENOSPC;
+  }
+  uint64_t* ukeys = d_keys ? d_keys : w.ukeys;
+  const float inv_gs = 1.0f / grid_size;
+  const int bs = 256;
+  const unsigned gb = (unsigned)cdiv(n, bs);
+  hipLaunchKernelGGL(vox_init_kernel, dim3(1), dim3(64), 0, stream, w.mm);
+  hipLaunchKernelGGL(vox_minmax_kernel, dim3(gb < 2048 ? gb : 2048), dim3(bs), 0, stream, d_coord,
+                     d_offset, n, b, grid_size, inv_gs, grid_mode, w.mm);
+  hipLaunchKernelGGL(vox_key_kernel, dim3(gb), dim3(bs), 0, stream, d_coord, d_offset, n, b,
+                     grid_size, inv_gs, grid_mode, hash_method, w.mm, w.keys, w.bc, d_grid_coord);
+  M3D_LAUNCH_CHECK();
+  int rc = unique_sorted(w.keys, n, ukeys, w.rep, w.inverse, w.count, w.uniq, w.uniq_bytes, stream);
+  if (rc != M3D_OK) return rc;
+  M3D_HIP(hipMemsetAsync(w.sums, 0, (size_t)n * c * sizeof(double), stream));
+  M3D_HIP(hipMemsetAsync(w.cnt, 0, (size_t)n * sizeof(int32_t), stream));
+  hipLaunchKernelGGL(vox_coords_kernel, dim3(gb), dim3(bs), 0, stream, w.rep, w.bc, w.count,
+                     reinterpret_cast<int4*>(d_voxel_coords));
+  hipLaunchKernelGGL(vox_accum_kernel, dim3(gb), dim3(bs), 0, stream, d_feat, w.inverse, n, c, w.sums,
+                     w.cnt, d_v2p_map);
+  hipLaunchKernelGGL(vox_mean_kernel, dim3((unsigned)cdiv(n * c, bs)), dim3(bs), 0, stream, w.sums,
+                     w.cnt, w.count, c, d_voxel_feats);
+  hipLaunchKernelGGL(vox_meta_kernel, dim3(1), dim3(64), 0, stream, w.mm, w.count, pad, d_meta);
+  M3D_LAUNCH_CHECK();
+  return M3D_OK;
+}

@@ -1,0 +1,219 @@
+"""Fused inference engine for the PPT SpUNet hot path:
+
+    voxelize -> kernel maps -> SpUNet forward (folded PDNorm, fused epilogues, concat-free decoder)
+             -> CLIP-text logits -> per-voxel argmax -> per-point labels
+
+Same inputs and outputs as the reference's DenseLanguageLitModule.forward + CLIPAlignmentEval.predict
+(mosaic3d/src/models/lightning_modules/language_module.py:197-207,314-328,
+ mosaic3d/src/models/losses/clip_alignment_loss.py:138-147), same network as
+spconv_unet_v1m3_pdnorm.py:380-414 in eval mode.  What is restructured for MI355X:
+
+* PDBatchNorm (eval) + context modulation is folded to one per-channel (scale, shift) and applied in
+  the convolution epilogue together with the residual add and ReLU (v1m3:57-68,121-140);
+* torch.cat((x, skip)) (v1m3:404) is never materialised: the convolution reads the two tensors as
+  two K-slabs;
+* the head runs per voxel and the labels are gathered through v2p_map (argmax commutes with the
+  row gather); the [N_pts, 768] clip_feat tensor is only produced on request.
+"""
+from typing import Dict, Optional, Sequence
+
+import torch
+
+from . import ops, sparse
+
+
+def _fold_norm(sd: Dict[str, torch.Tensor], prefix: str, cond_idx: int, context: Optional[torch.Tensor],
+               eps: float = 1e-3):
+    """(scale, shift) such that PDBatchNorm_eval(x) == scale * x + shift, folded in float64."""
+    key = f"{prefix}.bns.{cond_idx}" if f"{prefix}.bns.{cond_idx}.running_mean" in sd else f"{prefix}.bn"
+    mean = sd[f"{key}.running_mean"].double()
+    var = sd[f"{key}.running_var"].double()
+    w = sd[f"{key}.weight"].double() if f"{key}.weight" in sd else torch.ones_like(mean)
+    b = sd[f"{key}.bias"].double() if f"{key}.bias" in sd else torch.zeros_like(mean)
+    a = w / torch.sqrt(var + eps)
+    c = b - mean * a
+    mw = sd.get(f"{prefix}.modulation.1.weight")
+    if mw is not None:
+        mod = torch.nn.functional.linear(torch.nn.functional.silu(context.double()), mw.double(),
+                                         sd[f"{prefix}.modulation.1.bias"].double())
+        shift, scale = mod.chunk(2, dim=1)
+        a = a * (1.0 + scale[0])
+        c = c * (1.0 + scale[0]) + shift[0]
+    return a.float().contiguous(), c.float().contiguous()
+
+
+class _Conv:
+    __slots__ = ("w", "scale", "shift", "cout")
+
+    def __init__(self, w, scale, shift):
+        self.w, self.scale, self.shift = w, scale, shift
+        self.cout = w.shape[1]
+
+
+class _Level:
+    """Kernel maps of one resolution level."""
+    __slots__ = ("indices", "shape", "n", "subm", "down", "up", "pair_subm", "pair_fwd", "pair_bwd")
+
+
+class SpUNetEngine:
+    def __init__(self, model_or_state: object, cfg: Dict, condition: str = "ScanNet", device="cuda"):
+        """model_or_state: a PPT module (segmentation_amd.spunet.PPT or the reference's) or its state_dict
+        ('backbone.*' + 'embedding_table.weight').  cfg: channels / layers / conditions of the backbone."""
+        sd = model_or_state.state_dict() if hasattr(model_or_state, "state_dict") else dict(model_or_state)
+        sd = {k: v.detach().to("cpu") for k, v in sd.items()}
+        self.cfg = cfg
+        self.device = torch.device(device)
+        self.channels, self.layers = tuple(cfg["channels"]), tuple(cfg["layers"])
+        self.num_stages = len(self.layers) // 2
+        self.condition = condition
+        ci = list(cfg["conditions"]).index(condition)
+        ctx = sd["embedding_table.weight"][ci:ci + 1] if "embedding_table.weight" in sd else None
+        bsd = {k[len("backbone."):]: v for k, v in sd.items() if k.startswith("backbone.")}
+        self._sd = bsd
+
+        def conv(wname, nname=None, bias=None):
+            w = ops.pack_weight(bsd[wname]).to(self.device)
+            if nname is not None:
+                a, c = _fold_norm(bsd, nname, ci, ctx)
+            else:
+                a = None
+                c = bsd[bias].float().contiguous() if bias is not None and bias in bsd else None
+            return _Conv(w, None if a is None else a.to(self.device), None if c is None else c.to(self.device))
+
+        def block(prefix):
+            d = dict(conv1=conv(f"{prefix}.conv1.weight", f"{prefix}.bn1"),
+                     conv2=conv(f"{prefix}.conv2.weight", f"{prefix}.bn2"))
+            if f"{prefix}.proj_conv.weight" in bsd:
+                d["proj"] = conv(f"{prefix}.proj_conv.weight", f"{prefix}.proj_norm")
+            return d
+
+        ch, layers = self.channels, self.layers
+        self.stem = conv("conv_input.conv.weight", "conv_input.bn")
+        self.down = [conv(f"down.{s}.conv.weight", f"down.{s}.bn") for s in range(self.num_stages)]
+        self.up = [conv(f"up.{s}.conv.weight", f"up.{s}.bn") for s in range(self.num_stages)]
+        self.enc = [[block(f"enc.{s}.block{i}") for i in range(layers[s])] for s in range(self.num_stages)]
+        self.dec = [[block(f"dec.{s}.block{i}") for i in range(layers[len(ch) - s - 1])]
+                    for s in range(self.num_stages)]
+        self.final = conv("final.weight", None, "final.bias")
+        self.text = None
+        self.n_classes = 0
+        self.last_stats = {}
+
+    # ------------------------------------------------------------------ head
+    def set_text_embeddings(self, emb: torch.Tensor):
+        """emb [C, D] (rows are unit-norm CLIP text features, clip_alignment_loss.py:123-124)."""
+        emb = emb.detach().float().to(self.device)
+        c, d = emb.shape
+        if d != self.final.cout:
+            raise ValueError(f"text dim {d} does not match the backbone output {self.final.cout}")
+        cpad = 32 if c <= 32 else 64 if c <= 64 else 96 if c <= 96 else (c + 127) // 128 * 128
+        w = torch.zeros((1, cpad, d), dtype=torch.float32, device=self.device)
+        w[0, :c] = emb
+        self.text = _Conv(w.contiguous(), None, None)
+        self.n_classes = c
+        # folded head: logits = x96 . (E Wf)^T + E bf   (no nonlinearity between `final` and the head)
+        wf = self._sd["final.weight"].reshape(self.final.cout, -1).double().to(self.device)
+        wfold = torch.zeros((1, cpad, wf.shape[1]), dtype=torch.float32, device=self.device)
+        wfold[0, :c] = (emb.double() @ wf).float()
+        bfold = torch.zeros((cpad,), dtype=torch.float32, device=self.device)
+        if "final.bias" in self._sd:
+            bfold[:c] = (emb.double() @ self._sd["final.bias"].double().to(self.device)).float()
+        self.text_folded = _Conv(wfold.contiguous(), None, bfold.contiguous())
+
+    # ------------------------------------------------------------------ kernel maps
+    def build_levels(self, voxel_coords, spatial_shape):
+        levels = []
+        idx, shape = voxel_coords, list(spatial_shape)
+        for l in range(self.num_stages + 1):
+            lv = _Level()
+            lv.indices, lv.shape, lv.n = idx, shape, idx.shape[0]
+            lv.pair_subm = ops.subm_rulebook(idx, shape)
+            lv.subm = ops.build_schedule(lv.pair_subm, lv.n, idx, 1)
+            lv.down = lv.up = lv.pair_fwd = lv.pair_bwd = None
+            levels.append(lv)
+            if l < self.num_stages:
+                oi, oshape, pf, pb = ops.strided_rulebook(idx, shape)
+                lv.pair_fwd, lv.pair_bwd = pf, pb
+                lv.down = ops.build_schedule(pf, oi.shape[0], None, 0)
+                lv.up = ops.build_schedule(pb, lv.n, idx, 2)
+                idx, shape = oi, oshape
+        return levels
+
+    # ------------------------------------------------------------------ network
+    def _block(self, blk, x, sched, n, x2=None):
+        """BasicBlock with fused epilogues; (x, x2) are the two K-slabs of a concatenated input."""
+        if "proj" in blk:
+            p = blk["proj"]
+            res = ops.conv_fwd(x, p.w, None, n, in1=x2, scale=p.scale, shift=p.shift)
+        else:
+            res = x
+        c1, c2 = blk["conv1"], blk["conv2"]
+        t = ops.conv_fwd(x, c1.w, sched, n, in1=x2, scale=c1.scale, shift=c1.shift, relu=True)
+        return ops.conv_fwd(t, c2.w, sched, n, scale=c2.scale, shift=c2.shift, residual=res, relu=True)
+
+    def backbone(self, voxel_feats, levels, keep=None):
+        """SpUNetBase.forward after sparsify (v1m3:388-407).  Returns [N0, out_channels]."""
+        ns = self.num_stages
+        l0 = levels[0]
+        x = ops.conv_fwd(voxel_feats, self.stem.w, l0.subm, l0.n, scale=self.stem.scale,
+                         shift=self.stem.shift, relu=True)
+        if keep is not None:
+            keep["conv_input"] = x
+        skips = [x]
+        for s in range(ns):
+            d = self.down[s]
+            x = ops.conv_fwd(x, d.w, levels[s].down, levels[s + 1].n, scale=d.scale, shift=d.shift, relu=True)
+            if keep is not None:
+                keep[f"down.{s}"] = x
+            for blk in self.enc[s]:
+                x = self._block(blk, x, levels[s + 1].subm, levels[s + 1].n)
+            if keep is not None:
+                keep[f"enc.{s}"] = x
+            skips.append(x)
+        x = skips.pop(-1)
+        for s in reversed(range(ns)):
+            u = self.up[s]
+            x = ops.conv_fwd(x, u.w, levels[s].up, levels[s].n, scale=u.scale, shift=u.shift, relu=True)
+            if keep is not None:
+                keep[f"up.{s}"] = x
+            skip = skips.pop(-1)
+            for i, blk in enumerate(self.dec[s]):
+                x = self._block(blk, x, levels[s].subm, levels[s].n, x2=skip if i == 0 else None)
+            if keep is not None:
+                keep[f"dec.{s}"] = x
+        return x
+
+    def forward_features(self, coord, feat, offset, grid_size, keep=None):
+        """Whole path up to the per-voxel open-vocabulary features.  Returns (features [N0, D], vox dict)."""
+        vox = ops.voxelize(coord, feat, offset, grid_size, pad=128)
+        levels = self.build_levels(vox["voxel_coords"], vox["spatial_shape"])
+        x = self.backbone(vox["voxel_feats"], levels, keep)
+        f = self.final
+        out = ops.conv_fwd(x, f.w, None, x.shape[0], shift=f.shift)
+        if keep is not None:
+            keep["final"] = out
+            keep["levels"] = levels
+        self.last_stats = dict(n_points=int(coord.shape[0]), n_voxels=[lv.n for lv in levels])
+        return out, vox
+
+    @torch.no_grad()
+    def predict(self, coord, feat, offset, grid_size, fold_head=False, return_logits=False):
+        """Per-point labels (int64), like logits.max(1)[1] on clip_feat @ emb_target.T."""
+        if self.text is None:
+            raise RuntimeError("call set_text_embeddings() first")
+        if fold_head:
+            vox = ops.voxelize(coord, feat, offset, grid_size, pad=128)
+            levels = self.build_levels(vox["voxel_coords"], vox["spatial_shape"])
+            x = self.backbone(vox["voxel_feats"], levels)
+            t = self.text_folded
+            logits = ops.conv_fwd(x, t.w, None, x.shape[0], shift=t.shift)
+            self.last_stats = dict(n_points=int(coord.shape[0]), n_voxels=[lv.n for lv in levels])
+        else:
+            feats, vox = self.forward_features(coord, feat, offset, grid_size)
+            logits = ops.conv_fwd(feats, self.text.w, None, feats.shape[0])
+        vlabel = ops.argmax_rows(logits, self.n_classes)
+        plabel = ops.gather_labels(vlabel, vox["v2p_map"])
+        out = dict(pred=plabel, voxel_pred=vlabel, v2p_map=vox["v2p_map"], n_voxels=vox["n_voxels"])
+        if return_logits:
+            out["voxel_logits"] = logits[:, :self.n_classes]
+        return out

@@ -1,0 +1,254 @@
+"""Tensor-level wrappers of the C ABI: device pointers in, torch tensors out.
+
+PyTorch supplies device memory, the current HIP stream and nothing else; every operator below
+runs a hand-written gfx950 kernel from libm3d_hip.so."""
+import ctypes
+from dataclasses import dataclass
+from typing import Optional, Sequence
+
+import torch
+
+from . import _lib
+
+HASH = {"fnv": 0, "ravel": 1}
+GRID = {"div": 0, "recip": 1, "floor": 2}
+
+_workspaces = {}
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return ctypes.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _workspace(nbytes: int, device) -> torch.Tensor:
+    """One growing scratch buffer per (device, stream); kernels on a stream run in order, so
+    consecutive calls may share it."""
+    key = (torch.device(device).index, torch.cuda.current_stream().cuda_stream)
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(int(nbytes * 1.25), 1 << 20), dtype=torch.uint8, device=device)
+        _workspaces[key] = ws
+    return ws
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("segmentation_amd operators need tensors on an AMD GPU (cuda device); "
+                               "there is no CPU path")
+
+
+def _shape3(shape: Sequence[int]):
+    arr = (ctypes.c_int64 * 3)(*[int(s) for s in shape])
+    return arr
+
+
+# ----------------------------------------------------------------------------- voxelize
+def voxelize(coord, feat, offset, grid_size, pad=128, hash_method="fnv", grid_mode="div",
+             return_keys=False, return_grid_coord=False):
+    """Point.sparsify + mean_pooling on the GPU (reference: structure.py:197-251, :34-66).
+
+    offset: cumulative counts, with or without the leading 0 (misc.py:8-13), tensor or list.
+    Returns a dict with voxel_coords [N0,4] i32, voxel_feats [N0,C] f32, v2p_map [N] i64,
+    spatial_shape (list of 3), batch_size, optional keys [N0] (uint64 bit patterns in int64)."""
+    lib = _lib.load()
+    _need_cuda(coord, feat)
+    coord = coord.contiguous().float()
+    feat = feat.contiguous().float()
+    n, c = feat.shape
+    assert coord.shape == (n, 3)
+    off = torch.as_tensor(offset).detach().to("cpu", torch.int64).flatten()
+    if off.numel() == 0:
+        raise ValueError("offset must not be empty")
+    if int(off[0]) != 0:
+        off = torch.cat([torch.zeros(1, dtype=torch.int64), off])
+    if int(off[-1]) != n:
+        raise ValueError(f"offset[-1]={int(off[-1])} does not match the number of points {n}")
+    counts = off[1:] - off[:-1]
+    if (counts < 0).any():
+        raise ValueError("offset must be non-decreasing")
+    if n == 0:
+        raise ValueError("voxelize needs at least one point")
+    b = counts.numel()
+    batch_size = int(torch.nonzero(counts > 0).max()) + 1
+    dev = coord.device
+    off_d = off.to(dev)
+    voxel_coords = torch.empty((n, 4), dtype=torch.int32, device=dev)
+    voxel_feats = torch.empty((n, c), dtype=torch.float32, device=dev)
+    v2p = torch.empty((n,), dtype=torch.int64, device=dev)
+    keys = torch.empty((n,), dtype=torch.int64, device=dev) if return_keys else None
+    gc = torch.empty((n, 3), dtype=torch.int32, device=dev) if return_grid_coord else None
+    meta = torch.empty((16,), dtype=torch.int64, device=dev)
+    nb = lib.m3d_voxelize_workspace_bytes(n, c)
+    ws = _workspace(nb, dev)
+    rc = lib.m3d_voxelize(_ptr(coord), _ptr(feat), _ptr(off_d), n, c, b, float(grid_size), int(pad),
+                          HASH[hash_method], GRID[grid_mode], _ptr(voxel_coords), _ptr(voxel_feats),
+                          _ptr(v2p), _ptr(keys), _ptr(gc), _ptr(meta), _ptr(ws), ws.numel(), _stream())
+    _lib.check(rc, "m3d_voxelize")
+    m = meta.cpu().tolist()  # the one host sync of the voxelizer: output sizes are data dependent
+    n0 = m[0]
+    out = dict(voxel_coords=voxel_coords[:n0], voxel_feats=voxel_feats[:n0], v2p_map=v2p,
+               spatial_shape=[int(m[1]), int(m[2]), int(m[3])], batch_size=batch_size, n_voxels=n0,
+               grid_min=[int(m[4]), int(m[5]), int(m[6])])
+    if return_keys:
+        out["keys"] = keys[:n0]
+    if return_grid_coord:
+        out["grid_coord"] = gc
+    return out
+
+
+# ----------------------------------------------------------------------------- kernel maps
+def subm_rulebook(indices, spatial_shape):
+    """SubM k3 kernel map: pair [27, N] i32 (reference call sites: v1m3:98-117,205-212)."""
+    lib = _lib.load()
+    _need_cuda(indices)
+    indices = indices.contiguous()
+    assert indices.dtype == torch.int32 and indices.dim() == 2 and indices.shape[1] == 4
+    n = indices.shape[0]
+    pair = torch.empty((27, n), dtype=torch.int32, device=indices.device)
+    if n == 0:
+        return pair
+    ws = _workspace(lib.m3d_subm_rulebook_workspace_bytes(n), indices.device)
+    rc = lib.m3d_subm_rulebook(_ptr(indices), n, _shape3(spatial_shape), _ptr(pair), _ptr(ws),
+                               ws.numel(), _stream())
+    _lib.check(rc, "m3d_subm_rulebook")
+    return pair
+
+
+def strided_rulebook(indices, spatial_shape):
+    """k2 s2 p0 kernel map (v1m3:154-161).  Returns out_indices [M,4], out_shape, pair_fwd [8,M]
+    (a strided view), pair_bwd [8,N]."""
+    lib = _lib.load()
+    _need_cuda(indices)
+    indices = indices.contiguous()
+    assert indices.dtype == torch.int32 and indices.dim() == 2 and indices.shape[1] == 4
+    n = indices.shape[0]
+    if n == 0:
+        raise ValueError("strided_rulebook needs at least one voxel")
+    dev = indices.device
+    out_idx = torch.empty((n, 4), dtype=torch.int32, device=dev)
+    pf = torch.empty((8, n), dtype=torch.int32, device=dev)
+    pb = torch.empty((8, n), dtype=torch.int32, device=dev)
+    nout = torch.empty((1,), dtype=torch.int64, device=dev)
+    ws = _workspace(lib.m3d_strided_rulebook_workspace_bytes(n), dev)
+    rc = lib.m3d_strided_rulebook(_ptr(indices), n, _shape3(spatial_shape), _ptr(out_idx), _ptr(pf),
+                                  _ptr(pb), _ptr(nout), _ptr(ws), ws.numel(), _stream())
+    _lib.check(rc, "m3d_strided_rulebook")
+    m = int(nout.item())
+    out_shape = [int(s) // 2 for s in spatial_shape]
+    return out_idx[:m], out_shape, pf[:, :m], pb
+
+
+@dataclass
+class Schedule:
+    """Tile schedule of a kernel map (see include/m3d.h, m3d_build_schedule)."""
+    nbr: torch.Tensor        # [k, npad] i32
+    out_row: torch.Tensor    # [npad] i32
+    tile_mask: torch.Tensor  # [npad/32] i32 (bit k = offset k active in the tile)
+    n: int
+    npad: int
+    k: int
+
+
+def build_schedule(pair, n, indices=None, mode=0):
+    lib = _lib.load()
+    _need_cuda(pair)
+    assert pair.dtype == torch.int32 and pair.dim() == 2
+    k = pair.shape[0]
+    ld = pair.stride(0)
+    assert pair.stride(1) == 1 and ld >= n
+    dev = pair.device
+    npad = lib.m3d_schedule_npad(n)
+    nbr = torch.empty((k, npad), dtype=torch.int32, device=dev)
+    out_row = torch.empty((npad,), dtype=torch.int32, device=dev)
+    mask = torch.empty((npad // 32,), dtype=torch.int32, device=dev)
+    if indices is not None:
+        indices = indices.contiguous()
+        assert indices.dtype == torch.int32 and indices.shape == (n, 4)
+    ws = _workspace(lib.m3d_schedule_workspace_bytes(n), dev)
+    rc = lib.m3d_build_schedule(_ptr(pair), k, ld, n, _ptr(indices), int(mode), _ptr(nbr), _ptr(out_row),
+                                _ptr(mask), _ptr(ws), ws.numel(), _stream())
+    _lib.check(rc, "m3d_build_schedule")
+    return Schedule(nbr, out_row, mask, n, npad, k)
+
+
+# ----------------------------------------------------------------------------- convolution
+def pack_weight(weight):
+    """Reference layout [Cout, k0, k1, k2, Cin] -> kernel layout [K, Cout, Cin] (contiguous)."""
+    cout, cin = weight.shape[0], weight.shape[-1]
+    return weight.detach().reshape(cout, -1, cin).permute(1, 0, 2).contiguous().float()
+
+
+def conv_fwd(in0, weight_packed, sched: Optional[Schedule], n_out, in1=None, scale=None, shift=None,
+             residual=None, relu=False, out=None):
+    """out[row] = act(scale * sum_k W[k] . cat(in0, in1)[nbr[k][t]] + shift + residual[row]).
+
+    sched=None is the dense 1x1 case (Custom1x1Subm3d, structure.py:336-347)."""
+    lib = _lib.load()
+    _need_cuda(in0, weight_packed)
+    k, cout, cin = weight_packed.shape
+    c0 = in0.shape[1]
+    c1 = 0 if in1 is None else in1.shape[1]
+    if c0 + c1 != cin:
+        raise ValueError(f"input channels {c0}+{c1} do not match the weight's {cin}")
+    assert in0.is_contiguous() and in0.dtype == torch.float32
+    assert in1 is None or (in1.is_contiguous() and in1.dtype == torch.float32)
+    assert weight_packed.is_contiguous() and weight_packed.dtype == torch.float32
+    dev = in0.device
+    if out is None:
+        out = torch.empty((n_out, cout), dtype=torch.float32, device=dev)
+    assert out.dtype == torch.float32 and out.shape[0] == n_out and out.shape[1] >= cout and out.stride(1) == 1
+    ldo = out.stride(0)
+    for v in (scale, shift):
+        assert v is None or (v.is_contiguous() and v.dtype == torch.float32 and v.numel() == cout)
+    if residual is not None:
+        assert residual.is_contiguous() and residual.shape == (n_out, cout) and residual.dtype == torch.float32
+    if n_out == 0:
+        return out
+    if sched is None:
+        if k != 1:
+            raise ValueError("a convolution without a schedule must have one kernel offset")
+        if in0.shape[0] < n_out:
+            raise ValueError("dense conv: fewer input rows than output rows")
+        nbr = orow = mask = None
+        npad = lib.m3d_schedule_npad(n_out)
+    else:
+        if sched.k != k:
+            raise ValueError(f"schedule has {sched.k} kernel offsets, weight has {k}")
+        if sched.n != n_out:
+            raise ValueError(f"schedule covers {sched.n} rows, output has {n_out}")
+        nbr, orow, mask, npad = sched.nbr, sched.out_row, sched.tile_mask, sched.npad
+    ws = _workspace(lib.m3d_conv_workspace_bytes(n_out, cout, k), dev)
+    rc = lib.m3d_conv_fwd_f32(_ptr(in0), c0, _ptr(in1), c1, _ptr(weight_packed), k, cout, _ptr(nbr),
+                              _ptr(orow), _ptr(mask), n_out, npad, _ptr(scale), _ptr(shift),
+                              _ptr(residual), int(bool(relu)), _ptr(out), ldo, _ptr(ws), ws.numel(),
+                              _stream())
+    _lib.check(rc, "m3d_conv_fwd_f32")
+    return out
+
+
+# ----------------------------------------------------------------------------- head
+def argmax_rows(logits, n_classes):
+    lib = _lib.load()
+    _need_cuda(logits)
+    assert logits.dtype == torch.float32 and logits.stride(1) == 1
+    n = logits.shape[0]
+    label = torch.empty((n,), dtype=torch.int32, device=logits.device)
+    rc = lib.m3d_argmax_rows(_ptr(logits), n, int(n_classes), logits.stride(0), _ptr(label), _stream())
+    _lib.check(rc, "m3d_argmax_rows")
+    return label
+
+
+def gather_labels(voxel_label, v2p_map):
+    lib = _lib.load()
+    _need_cuda(voxel_label, v2p_map)
+    assert voxel_label.dtype == torch.int32 and v2p_map.dtype == torch.int64
+    n = v2p_map.shape[0]
+    out = torch.empty((n,), dtype=torch.int64, device=v2p_map.device)
+    rc = lib.m3d_gather_labels(_ptr(voxel_label), _ptr(v2p_map.contiguous()), n, _ptr(out), _stream())
+    _lib.check(rc, "m3d_gather_labels")
+    return out

@@ -1,0 +1,216 @@
+"""SpUNet (v1m3 PDNorm) + PPT wrapper built on segmentation_amd.sparse, with the reference's
+parameter names, so that a Mosaic3D checkpoint's `net.*` state dict loads unchanged.
+
+Layer list, channel plan and forward order follow
+mosaic3d/src/models/networks/spunet/spconv_unet_v1m3_pdnorm.py:224-414 and
+mosaic3d/src/models/networks/ppt/model.py:7-22; voxelisation follows Point.sparsify
+(mosaic3d/src/models/utils/structure.py:197-251) but runs on the GPU (ops.voxelize).
+
+This module is the layer-by-layer (unfused) path; segmentation_amd.engine runs the same network
+with folded norms and fused epilogues."""
+from collections import OrderedDict
+from typing import Dict, Sequence
+
+import torch
+import torch.nn as nn
+
+from . import ops, sparse
+
+CONDITIONS = ("ScanNet", "ARKitScenes", "Matterport3D", "Structured3D", "ScanNetPP")
+SPUNET34C = dict(in_channels=3, out_channels=768, base_channels=32, context_channels=256,
+                 channels=(32, 64, 128, 256, 256, 128, 96, 96), layers=(2, 3, 4, 6, 2, 2, 2, 2),
+                 conditions=CONDITIONS)
+SPUNET18A = dict(SPUNET34C, channels=(32, 64, 128, 256, 128, 128, 96, 96), layers=(2, 2, 2, 2, 2, 2, 2, 2))
+
+
+class PDBatchNorm(nn.Module):
+    """Per-dataset BatchNorm1d + context modulation (v1m3:19-68)."""
+
+    def __init__(self, num_features, context_channels=256, eps=1e-3, momentum=0.01,
+                 conditions=CONDITIONS, decouple=True, adaptive=False, affine=True):
+        super().__init__()
+        self.conditions = tuple(conditions)
+        self.decouple, self.adaptive, self.affine = decouple, adaptive, affine
+        mk = lambda: nn.BatchNorm1d(num_features, eps=eps, momentum=momentum, affine=affine)
+        if decouple:
+            self.bns = nn.ModuleList([mk() for _ in self.conditions])
+        else:
+            self.bn = mk()
+        if adaptive:
+            self.modulation = nn.Sequential(nn.SiLU(), nn.Linear(context_channels, 2 * num_features, bias=True))
+
+    def pick(self, condition):
+        if not self.decouple:
+            return self.bn
+        if condition not in self.conditions:
+            raise AssertionError(f"unknown condition {condition!r}")
+        return self.bns[self.conditions.index(condition)]
+
+    def forward(self, feat, condition=None, context=None):
+        feat = self.pick(condition)(feat)
+        if self.adaptive:
+            assert context is not None
+            shift, scale = self.modulation(context).chunk(2, dim=1)
+            feat = feat * (1.0 + scale) + shift
+        return feat
+
+
+class ConvNormAct(nn.Module):
+    """conv -> PDBatchNorm -> ReLU; the shape of conv_input / down[s] / up[s] (v1m3:143-221)."""
+
+    def __init__(self, conv, norm):
+        super().__init__()
+        self.conv = conv
+        self.bn = norm
+        self.relu = nn.ReLU()
+
+    def forward(self, x):
+        x, condition, context = x
+        out = self.conv(x)
+        return out.replace_feature(self.relu(self.bn(out.features, condition, context)))
+
+
+class BasicBlock(sparse.SparseModule):
+    """Residual block of two SubM k3 convolutions (v1m3:71-140)."""
+
+    def __init__(self, in_channels, embed_channels, norm_fn, indice_key):
+        super().__init__()
+        self.in_channels, self.embed_channels = in_channels, embed_channels
+        if in_channels != embed_channels:
+            self.proj_conv = sparse.SparseConv3d(in_channels, embed_channels, kernel_size=1, bias=False)
+            self.proj_norm = norm_fn(embed_channels)
+        self.conv1 = sparse.SubMConv3d(in_channels, embed_channels, kernel_size=3, padding=1, bias=False,
+                                       indice_key=indice_key)
+        self.bn1 = norm_fn(embed_channels)
+        self.relu = nn.ReLU()
+        self.conv2 = sparse.SubMConv3d(embed_channels, embed_channels, kernel_size=3, padding=1, bias=False,
+                                       indice_key=indice_key)
+        self.bn2 = norm_fn(embed_channels)
+
+    def forward(self, x):
+        x, condition, context = x
+        out = self.conv1(x)
+        out = out.replace_feature(self.relu(self.bn1(out.features, condition, context)))
+        out = self.conv2(out)
+        feats = self.bn2(out.features, condition, context)
+        if self.in_channels == self.embed_channels:
+            res = x.features
+        else:
+            res = self.proj_norm(self.proj_conv(x).features, condition, context)
+        return out.replace_feature(self.relu(feats + res)), condition, context
+
+
+class SpUNet(nn.Module):
+    def __init__(self, in_channels=3, out_channels=768, num_classes=0, base_channels=32, context_channels=256,
+                 channels=SPUNET34C["channels"], layers=SPUNET34C["layers"], conditions=CONDITIONS,
+                 zero_init=True, norm_decouple=True, norm_adaptive=True, norm_affine=True):
+        super().__init__()
+        assert len(layers) % 2 == 0 and len(layers) == len(channels)
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.base_channels, self.channels, self.layers = base_channels, tuple(channels), tuple(layers)
+        self.num_stages = len(layers) // 2
+        self.conditions = tuple(conditions)
+        self.zero_init = zero_init
+        norm = lambda c: PDBatchNorm(c, context_channels, 1e-3, 0.01, self.conditions, norm_decouple,
+                                     norm_adaptive, norm_affine)
+        ch = self.channels
+        self.conv_input = ConvNormAct(
+            sparse.SubMConv3d(in_channels, base_channels, kernel_size=3, padding=1, bias=False, indice_key="stem"),
+            norm(base_channels))
+        self.down, self.up, self.enc, self.dec = nn.ModuleList(), nn.ModuleList(), nn.ModuleList(), nn.ModuleList()
+        enc_c, dec_c = base_channels, ch[-1]
+        for s in range(self.num_stages):
+            self.down.append(ConvNormAct(
+                sparse.SparseConv3d(enc_c, ch[s], kernel_size=2, stride=2, bias=False, indice_key=f"spconv{s + 1}"),
+                norm(ch[s])))
+            self.enc.append(sparse.SparseSequential(OrderedDict(
+                (f"block{i}", BasicBlock(ch[s], ch[s], norm, f"subm{s + 1}")) for i in range(layers[s]))))
+            self.up.append(ConvNormAct(
+                sparse.SparseInverseConv3d(ch[len(ch) - s - 2], dec_c, kernel_size=2, bias=False,
+                                           indice_key=f"spconv{s + 1}"),
+                norm(dec_c)))
+            self.dec.append(sparse.SparseSequential(OrderedDict(
+                (f"block{i}", BasicBlock(dec_c + enc_c if i == 0 else dec_c, dec_c, norm, f"subm{s}"))
+                for i in range(layers[len(ch) - s - 1]))))
+            enc_c, dec_c = ch[s], ch[len(ch) - s - 2]
+        final_out = num_classes if num_classes > 0 else out_channels
+        self.final = sparse.SparseConv3d(ch[-1], final_out, kernel_size=1, bias=True)
+        self.apply(self._init_weights)
+
+    def _init_weights(self, m):
+        """v1m3:362-378."""
+        if isinstance(m, nn.Linear):
+            nn.init.trunc_normal_(m.weight, std=0.02)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+        elif isinstance(m, sparse.SubMConv3d):
+            nn.init.trunc_normal_(m.weight, std=0.02)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+        elif isinstance(m, nn.BatchNorm1d):
+            if m.affine:
+                nn.init.constant_(m.bias, 0)
+                nn.init.constant_(m.weight, 1.0)
+        elif isinstance(m, PDBatchNorm):
+            if self.zero_init and m.adaptive:
+                nn.init.constant_(m.modulation[-1].weight, 0)
+                nn.init.constant_(m.modulation[-1].bias, 0)
+
+    def sparsify(self, input_dict, pad=128):
+        vox = ops.voxelize(input_dict["coord"], input_dict["feat"], input_dict["offset"],
+                           input_dict["grid_size"], pad=pad)
+        x = sparse.SparseConvTensor(vox["voxel_feats"], vox["voxel_coords"], vox["spatial_shape"],
+                                    vox["batch_size"])
+        return x, vox
+
+    def forward(self, input_dict):
+        """Returns dict(sparse_conv_feat, feat [N0, out], v2p_map [N_pts]) -- the fields of the
+        reference's Point that the head reads (language_module.py:202-207)."""
+        x, vox = self.sparsify(input_dict)
+        condition = input_dict["condition"][0]
+        context = input_dict.get("context")
+        x = self.conv_input([x, condition, context])
+        if context is not None:
+            context = context.to(x.features.dtype)
+        skips = [x]
+        for s in range(self.num_stages):
+            x = self.down[s]([x, condition, context])
+            x, _, _ = self.enc[s]([x, condition, context])
+            skips.append(x)
+        x = skips.pop(-1)
+        for s in reversed(range(self.num_stages)):
+            x = self.up[s]([x, condition, context])
+            skip = skips.pop(-1)
+            x = x.replace_feature(torch.cat((x.features, skip.features), dim=1))
+            x, _, _ = self.dec[s]([x, condition, context])
+        x = self.final(x)
+        return dict(sparse_conv_feat=x, feat=x.features, v2p_map=vox["v2p_map"], voxel=vox)
+
+
+class PPT(nn.Module):
+    """Context embedding per dataset condition in front of the backbone (ppt/model.py:7-22)."""
+
+    def __init__(self, backbone: nn.Module, conditions: Sequence[str] = CONDITIONS, context_channels=256):
+        super().__init__()
+        self.backbone = backbone
+        self.conditions = tuple(conditions)
+        self.embedding_table = nn.Embedding(len(self.conditions), context_channels)
+
+    def forward(self, batch_dict: Dict):
+        condition = batch_dict["condition"][0]
+        assert condition in self.conditions
+        idx = torch.tensor([self.conditions.index(condition)], device=batch_dict["coord"].device)
+        batch_dict["context"] = self.embedding_table(idx)
+        return self.backbone(batch_dict)
+
+
+def load_oracle_params(model: PPT, params: Dict[str, torch.Tensor]):
+    """Load a flat parameter dict keyed like the reference backbone's state_dict (+ 'embedding_table.weight')."""
+    sd = {}
+    for k, v in params.items():
+        sd[k if k.startswith("embedding_table") else "backbone." + k] = v
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    missing = [m for m in missing if not m.endswith("num_batches_tracked")]
+    if missing or unexpected:
+        raise KeyError(f"parameter mismatch: missing={missing[:5]} unexpected={unexpected[:5]}")
+    return model

@@ -1,0 +1,86 @@
+"""GPU kernel maps (m3d_subm_rulebook / m3d_strided_rulebook / m3d_build_schedule) against the CPU
+oracle: bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from segmentation_amd import ops, scenes
+
+pytestmark = pytest.mark.gpu
+
+
+def _voxels(seed, target, batch=1):
+    if batch == 1:
+        sc = scenes.make_scene(seed=seed, target_voxels=target)
+        off = np.array([0, sc["coord"].shape[0]], dtype=np.int64)
+        return oracle.sparsify(sc["coord"], sc["feat"], off, 0.02)
+    b = scenes.make_batch(range(seed, seed + batch), target_voxels=target)
+    return oracle.sparsify(b["coord"], b["feat"], b["offset"], 0.02)
+
+
+@pytest.mark.parametrize("seed,target,batch", [(0, 2000, 1), (1, 40000, 1), (2, 5000, 3)])
+def test_subm_rulebook_bit_exact(device, seed, target, batch):
+    sp = _voxels(seed, target, batch)
+    idx = torch.from_numpy(sp["voxel_coords"]).to(device)
+    pair = ops.subm_rulebook(idx, sp["spatial_shape"])
+    ref = oracle.subm_rulebook(sp["voxel_coords"], sp["spatial_shape"])
+    assert np.array_equal(pair.cpu().numpy(), ref)
+
+
+def test_subm_rulebook_respects_bounds_and_batches(device):
+    # neighbours across the spatial boundary or in another batch must not pair
+    idx = np.array([[0, 0, 0, 0], [0, 0, 0, 1], [1, 0, 0, 1], [0, 3, 3, 3], [1, 3, 3, 2]], dtype=np.int32)
+    pair = ops.subm_rulebook(torch.from_numpy(idx).to(device), [4, 4, 4])
+    assert np.array_equal(pair.cpu().numpy(), oracle.subm_rulebook(idx, [4, 4, 4]))
+
+
+@pytest.mark.parametrize("seed,target,batch", [(0, 2000, 1), (1, 40000, 1), (2, 5000, 3)])
+def test_strided_rulebook_chain_bit_exact(device, seed, target, batch):
+    sp = _voxels(seed, target, batch)
+    idx_ref, shape = sp["voxel_coords"], sp["spatial_shape"]
+    idx = torch.from_numpy(idx_ref).to(device)
+    for level in range(4):
+        oi, oshape, pf, pb = ops.strided_rulebook(idx, shape)
+        roi, roshape, rpf, rpb = oracle.strided_rulebook(idx_ref, shape)
+        assert oshape == roshape
+        assert np.array_equal(oi.cpu().numpy(), roi)
+        assert np.array_equal(pf.cpu().numpy(), rpf)
+        assert np.array_equal(pb.cpu().numpy(), rpb)
+        idx, idx_ref, shape = oi.contiguous(), roi, oshape
+
+
+def test_strided_rulebook_drops_rows_outside_the_output_shape(device):
+    idx = np.array([[0, 4, 0, 0], [0, 0, 0, 0], [0, 1, 1, 1], [0, 2, 3, 2]], dtype=np.int32)  # shape 5 -> out 2
+    oi, oshape, pf, pb = ops.strided_rulebook(torch.from_numpy(idx).to(device), [5, 5, 5])
+    roi, roshape, rpf, rpb = oracle.strided_rulebook(idx, [5, 5, 5])
+    assert np.array_equal(oi.cpu().numpy(), roi) and np.array_equal(pf.cpu().numpy(), rpf)
+    assert np.array_equal(pb.cpu().numpy(), rpb)
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_schedule_is_a_permutation_of_the_kernel_map(device, mode):
+    sp = _voxels(3, 9000)
+    idx = torch.from_numpy(sp["voxel_coords"]).to(device)
+    n = idx.shape[0]
+    if mode == 2:
+        _, _, _, pair = ops.strided_rulebook(idx, sp["spatial_shape"])
+    else:
+        pair = ops.subm_rulebook(idx, sp["spatial_shape"])
+    sched = ops.build_schedule(pair, n, idx if mode else None, mode)
+    torch.cuda.synchronize()
+    orow = sched.out_row.cpu().numpy()
+    nbr = sched.nbr.cpu().numpy()
+    mask = sched.tile_mask.cpu().numpy().view(np.uint32)
+    p = pair.cpu().numpy()
+    assert sched.npad % 128 == 0 and sched.npad >= n
+    assert np.array_equal(np.sort(orow[:n]), np.arange(n)) and (orow[n:] == -1).all()
+    assert np.array_equal(nbr[:, :n], p[:, orow[:n]]) and (nbr[:, n:] == -1).all()
+    ref_mask = np.zeros(sched.npad // 32, dtype=np.uint32)
+    valid = (nbr >= 0).reshape(nbr.shape[0], -1, 32).any(2)
+    for k in range(nbr.shape[0]):
+        ref_mask |= (valid[k].astype(np.uint32) << np.uint32(k))
+    assert np.array_equal(mask, ref_mask)
+    if mode == 2:  # rows grouped by their single active kernel offset
+        kk = np.argmax(p[:, orow[:n]] >= 0, axis=0)
+        assert (np.diff(kk) >= 0).all()

@@ -1,0 +1,110 @@
+"""GPU voxelizer (m3d_voxelize through the C ABI) against the CPU oracle and the reference's golden
+vectors: keys, voxel order, coordinates and v2p_map bit-exact; means within 1e-6."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from segmentation_amd import ops, scenes
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(coord, feat, offset, grid, device, **kw):
+    out = ops.voxelize(torch.from_numpy(coord).to(device), torch.from_numpy(feat).to(device), offset, grid,
+                       return_keys=True, return_grid_coord=True, **kw)
+    torch.cuda.synchronize()
+    return out
+
+
+def _check(out, sp, hash_method):
+    assert out["spatial_shape"] == sp["spatial_shape"]
+    assert out["batch_size"] == sp["batch_size"]
+    assert np.array_equal(out["grid_coord"].cpu().numpy(), sp["grid_coord"])
+    assert np.array_equal(out["voxel_coords"].cpu().numpy(), sp["voxel_coords"])
+    assert np.array_equal(out["v2p_map"].cpu().numpy(), sp["v2p_map"])
+    keys = out["keys"].cpu().numpy().view(np.uint64)
+    assert np.array_equal(keys, sp["key"].astype(np.uint64))
+    np.testing.assert_allclose(out["voxel_feats"].cpu().numpy(), sp["voxel_feats"], rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("name", ["s1", "s2", "s3"])
+@pytest.mark.parametrize("hm", ["fnv", "ravel"])
+def test_golden_reference_vectors(golden_voxelize, device, name, hm):
+    g = golden_voxelize
+    coord, feat, off = g[f"vox_{name}_coord"], g[f"vox_{name}_feat"], g[f"vox_{name}_offset"]
+    grid = float(g[f"vox_{name}_grid"][0])
+    out = _run(coord, feat, off, grid, device, hash_method=hm)
+    pre = f"vox_{name}_{hm}_"
+    assert np.array_equal(out["voxel_coords"].cpu().numpy(), g[pre + "voxel_coords"])
+    assert np.array_equal(out["v2p_map"].cpu().numpy(), g[pre + "v2p_map"])
+    assert out["spatial_shape"] == g[pre + "spatial_shape"].tolist()
+    assert out["batch_size"] == int(g[pre + "batch_size"][0])
+    _check(out, oracle.sparsify(coord, feat, off, grid, hash_method=hm), hm)
+
+
+@pytest.mark.parametrize("seed,target", [(0, 3000), (1, 60000)])
+def test_scene_vs_oracle(device, seed, target):
+    sc = scenes.make_scene(seed=seed, target_voxels=target)
+    off = np.array([0, sc["coord"].shape[0]], dtype=np.int64)
+    out = _run(sc["coord"], sc["feat"], off, 0.02, device)
+    _check(out, oracle.sparsify(sc["coord"], sc["feat"], off, 0.02), "fnv")
+
+
+def test_batch_with_empty_sample_and_offset_without_leading_zero(device):
+    rng = np.random.default_rng(3)
+    coord = (rng.random((900, 3)) * 1.5 - 0.7).astype(np.float32)
+    feat = rng.standard_normal((900, 6)).astype(np.float32)
+    off = np.array([400, 400, 900], dtype=np.int64)  # second sample empty, no leading 0 (misc.py:8-13)
+    out = _run(coord, feat, off, 0.05, device)
+    _check(out, oracle.sparsify(coord, feat, off, 0.05), "fnv")
+
+
+def test_single_point_and_all_points_in_one_voxel(device):
+    coord = np.array([[0.3, -0.2, 0.1]], dtype=np.float32)
+    feat = np.array([[1.0, 2.0, 3.0]], dtype=np.float32)
+    out = _run(coord, feat, np.array([0, 1]), 0.02, device)
+    _check(out, oracle.sparsify(coord, feat, np.array([0, 1]), 0.02), "fnv")
+    coord = np.full((257, 3), 0.011, dtype=np.float32)
+    feat = np.arange(257 * 3, dtype=np.float32).reshape(257, 3)
+    out = _run(coord, feat, np.array([0, 257]), 0.02, device)
+    assert out["n_voxels"] == 1
+    _check(out, oracle.sparsify(coord, feat, np.array([0, 257]), 0.02), "fnv")
+
+
+def test_negative_coordinates_truncate_toward_zero(device):
+    # voxels straddling 0 are double width under the trunc rule (structure.py:219)
+    coord = np.array([[-0.019, 0.0, 0.0], [0.019, 0.0, 0.0], [-0.021, 0.0, 0.0], [0.021, 0.0, 0.0]], np.float32)
+    feat = np.eye(4, 3, dtype=np.float32)
+    out = _run(coord, feat, np.array([0, 4]), 0.02, device)
+    sp = oracle.sparsify(coord, feat, np.array([0, 4]), 0.02)
+    assert sp["voxel_coords"].shape[0] == 3
+    _check(out, sp, "fnv")
+
+
+def test_recip_grid_mode(device):
+    sc = scenes.make_scene(seed=2, target_voxels=2000)
+    off = np.array([0, sc["coord"].shape[0]], dtype=np.int64)
+    out = _run(sc["coord"], sc["feat"], off, 0.02, device, grid_mode="recip")
+    _check(out, oracle.sparsify(sc["coord"], sc["feat"], off, 0.02, grid_mode="recip"), "fnv")
+
+
+def test_full_size_properties(device):
+    """At the benchmark's size the oracle is not run; check size-independent properties instead."""
+    sc = scenes.make_scene(seed=0, target_voxels=250_000)
+    n = sc["coord"].shape[0]
+    out = _run(sc["coord"], sc["feat"], np.array([0, n]), 0.02, device)
+    keys = out["keys"].cpu().numpy().view(np.uint64)
+    assert (np.diff(keys.astype(np.float64)) >= 0).all() and len(np.unique(keys)) == len(keys)  # sorted, unique
+    v2p = out["v2p_map"].cpu().numpy()
+    n0 = out["n_voxels"]
+    assert v2p.min() == 0 and v2p.max() == n0 - 1 and len(np.unique(v2p)) == n0
+    # every point's grid coordinate equals its voxel's coordinate; keys are the FNV of the coordinates
+    vc = out["voxel_coords"].cpu().numpy()
+    gc = out["grid_coord"].cpu().numpy()
+    assert np.array_equal(vc[v2p][:, 1:], gc)
+    assert np.array_equal(oracle.fnv_hash_vec(vc), keys)
+    # means: sum over voxels of count * mean == sum over points
+    cnt = np.bincount(v2p, minlength=n0)
+    vf = out["voxel_feats"].cpu().numpy().astype(np.float64)
+    np.testing.assert_allclose((vf * cnt[:, None]).sum(0), sc["feat"].astype(np.float64).sum(0), rtol=1e-5, atol=1e-2)
