@@ -344,6 +344,7 @@ using namespace m3d;
 
 extern "C" size_t m3d_conv_workspace_bytes(int64_t n, int cout, int k) {
   const int64_t npad = m3d_schedule_npad(n);
+  if (cout <= 0 || cout % 32 != 0) return 256;  // served by the direct kernel, which needs no scratch
   ConvPlan p = plan_conv(npad, cout, k);
   if (p.nz <= 1) return 256;
   return align_up((size_t)p.nz * npad * cout * sizeof(float));
