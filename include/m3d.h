@@ -86,19 +86,22 @@ int m3d_subm_rulebook(const int32_t* d_indices, int64_t n, const int64_t spatial
  *   d_pair_fwd    [8,n]  i32  pair_fwd[k][o] = i or -1 (column stride n)
  *   d_pair_bwd    [8,n]  i32  pair_bwd[k][i] = o or -1
  *   d_n_out       [1]    i64
+ *   batch_size: SparseConvTensor.batch_size (every batch index must be < batch_size)
  */
 size_t m3d_strided_rulebook_workspace_bytes(int64_t n);
 int m3d_strided_rulebook(const int32_t* d_indices, int64_t n, const int64_t spatial_shape[3],
-                         int32_t* d_out_indices, int32_t* d_pair_fwd, int32_t* d_pair_bwd,
+                         int batch_size, int32_t* d_out_indices, int32_t* d_pair_fwd, int32_t* d_pair_bwd,
                          int64_t* d_n_out, void* d_ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Tile schedule of a kernel map: the order in which the convolution kernel walks output rows.
  * Has no counterpart in the reference (spconv keeps this inside its implicit-GEMM planner).
  *   d_pair [k,ld] i32  canonical kernel map (ld = column stride, n valid columns)
- *   d_indices [n,4]    coordinates of the OUTPUT rows (used for the spatial sort), may be NULL
- *   mode 0: identity order; 1: Morton order of d_indices; 2: group rows by their single active
- *           kernel offset (inverse conv), Morton inside a group
+ *   d_indices [n,4]    coordinates of the OUTPUT rows (mode 1 only, else may be NULL)
+ *   spatial_shape, batch_size: bounds of d_indices (mode 1; spatial_shape may be NULL)
+ *   d_base_order [n]   optional starting permutation of the rows (NULL = identity)
+ *   mode 0: the base order as is; 1: Morton order of d_indices; 2: rows grouped by their first
+ *           active kernel offset (inverse conv), base order kept inside a group
  * outputs, npad = m3d_schedule_npad(n):
  *   d_nbr      [k,npad] i32  nbr[k][t] = pair[k][row(t)], -1 in the padding
  *   d_out_row  [npad]   i32  row(t), -1 in the padding
@@ -107,7 +110,8 @@ int m3d_strided_rulebook(const int32_t* d_indices, int64_t n, const int64_t spat
 int64_t m3d_schedule_npad(int64_t n);
 size_t m3d_schedule_workspace_bytes(int64_t n);
 int m3d_build_schedule(const int32_t* d_pair, int k, int64_t ld, int64_t n,
-                       const int32_t* d_indices, int mode, int32_t* d_nbr, int32_t* d_out_row,
+                       const int32_t* d_indices, const int64_t* spatial_shape, int batch_size,
+                       int mode, const int32_t* d_base_order, int32_t* d_nbr, int32_t* d_out_row,
                        uint32_t* d_tile_mask, void* d_ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------

@@ -66,6 +66,12 @@ __host__ __device__ inline uint64_t mix64(uint64_t x) {
   return x;
 }
 
+static inline int bits_for(uint64_t max_value) {  // number of bits needed to represent max_value
+  int b = 0;
+  while (max_value) { ++b; max_value >>= 1; }
+  return b < 1 ? 1 : b;
+}
+
 static inline uint64_t next_pow2(uint64_t v) {
   uint64_t p = 1;
   while (p < v) p <<= 1;
@@ -87,7 +93,8 @@ int sort_pairs(uint64_t* d_keys, uint32_t* d_vals, uint64_t* d_keys_alt, uint32_
 // np.unique(keys, return_inverse=True) plus one representative input index per unique key.
 //   d_keys [n] input; outputs: d_ukeys [n] ascending unique keys, d_rep [n] an input index
 //   holding each unique key, d_inverse [n] rank of every input key, d_count [1] number of uniques.
-int unique_sorted(const uint64_t* d_keys, int64_t n, uint64_t* d_ukeys, int32_t* d_rep,
+//   nbits: number of low key bits that can be non-zero (sorting passes are skipped above it).
+int unique_sorted(const uint64_t* d_keys, int64_t n, int nbits, uint64_t* d_ukeys, int32_t* d_rep,
                   int32_t* d_inverse, int* d_count, void* d_ws, size_t ws_bytes,
                   hipStream_t stream);
 

@@ -21,7 +21,7 @@ void set_error(const char* fmt, ...) {
 const char* get_error() { return g_err; }
 
 // ------------------------------------------------------------------------------ radix sort
-constexpr int kWaveItems = 1024;   // elements ranked by one wave per pass
+constexpr int kWaveItems = 512;    // elements ranked by one wave per pass
 constexpr int kSortBlock = 256;    // 4 waves per workgroup
 constexpr int kRounds = kWaveItems / 64;
 
@@ -46,41 +46,63 @@ __global__ __launch_bounds__(kSortBlock) void radix_hist_kernel(
     for (int i = lane; i < 256; i += 64) counts[(int64_t)i * nchunks + chunk] = h[wave][i];
 }
 
-// Exclusive prefix sum over `total` u32 entries, one workgroup of 1024 threads.
-__global__ __launch_bounds__(1024) void scan_exclusive_kernel(uint32_t* __restrict__ data,
-                                                               int64_t total) {
-  __shared__ uint32_t part[1024];
-  const int t = threadIdx.x;
-  const int64_t per = (total + 1023) / 1024;
-  const int64_t lo = t * per;
-  const int64_t hi = lo + per < total ? lo + per : total;
+// One workgroup per digit: exclusive prefix over that digit's per-chunk counts (in place) and the
+// digit's total.  The 256 digit totals are turned into digit bases inside the scatter kernel.
+__global__ __launch_bounds__(256) void radix_scan_kernel(uint32_t* __restrict__ counts,
+                                                         uint32_t* __restrict__ totals, int nchunks) {
+  __shared__ uint32_t part[256];
+  const int d = blockIdx.x, t = threadIdx.x;
+  uint32_t* row = counts + (int64_t)d * nchunks;
+  const int per = (nchunks + 255) / 256;
+  const int lo = t * per;
+  const int hi = lo + per < nchunks ? lo + per : nchunks;
   uint32_t s = 0;
-  for (int64_t i = lo; i < hi; ++i) s += data[i];
+  for (int i = lo; i < hi; ++i) s += row[i];
   part[t] = s;
   __syncthreads();
-  for (int off = 1; off < 1024; off <<= 1) {
-    uint32_t v = t >= off ? part[t - off] : 0;
+  for (int off = 1; off < 256; off <<= 1) {
+    const uint32_t v = t >= off ? part[t - off] : 0;
     __syncthreads();
     part[t] += v;
     __syncthreads();
   }
-  uint32_t run = part[t] - s;  // exclusive prefix of this thread's segment
-  for (int64_t i = lo; i < hi; ++i) {
-    uint32_t v = data[i];
-    data[i] = run;
+  uint32_t run = part[t] - s;
+  for (int i = lo; i < hi; ++i) {
+    const uint32_t v = row[i];
+    row[i] = run;
     run += v;
   }
+  if (t == 255) totals[d] = part[255];
 }
 
 __global__ __launch_bounds__(kSortBlock) void radix_scatter_kernel(
     const uint64_t* __restrict__ kin, const uint32_t* __restrict__ vin,
     uint64_t* __restrict__ kout, uint32_t* __restrict__ vout, const int* __restrict__ d_count,
-    int shift, const uint32_t* __restrict__ offsets, int nchunks) {
+    int shift, const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ totals,
+    int nchunks) {
   __shared__ uint32_t run_s[kSortBlock / 64][256];
+  __shared__ uint32_t base_s[256];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int chunk = blockIdx.x * (kSortBlock / 64) + wave;
+  {  // exclusive scan of the 256 digit totals (kSortBlock == 256 threads, one digit each)
+    const int t = threadIdx.x;
+    const uint32_t own = totals[t];
+    base_s[t] = own;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+      const uint32_t v = t >= off ? base_s[t - off] : 0;
+      __syncthreads();
+      base_s[t] += v;
+      __syncthreads();
+    }
+    const uint32_t excl = base_s[t] - own;
+    __syncthreads();
+    base_s[t] = excl;
+    __syncthreads();
+  }
   if (chunk < nchunks)
-    for (int i = lane; i < 256; i += 64) run_s[wave][i] = offsets[(int64_t)i * nchunks + chunk];
+    for (int i = lane; i < 256; i += 64)
+      run_s[wave][i] = base_s[i] + offsets[(int64_t)i * nchunks + chunk];
   __syncthreads();
   if (chunk >= nchunks) return;
   volatile uint32_t* run = run_s[wave];
@@ -113,7 +135,7 @@ __global__ __launch_bounds__(kSortBlock) void radix_scatter_kernel(
 
 size_t sort_pairs_ws_bytes(int64_t nmax) {
   int64_t nchunks = cdiv(nmax > 0 ? nmax : 1, kWaveItems);
-  return align_up((size_t)nchunks * 256 * sizeof(uint32_t));
+  return align_up((size_t)nchunks * 256 * sizeof(uint32_t)) + align_up(256 * sizeof(uint32_t));
 }
 
 int sort_pairs(uint64_t* d_keys, uint32_t* d_vals, uint64_t* d_keys_alt, uint32_t* d_vals_alt,
@@ -126,6 +148,8 @@ int sort_pairs(uint64_t* d_keys, uint32_t* d_vals, uint64_t* d_keys_alt, uint32_
     return M3D_ENOSPC;
   }
   uint32_t* counts = static_cast<uint32_t*>(d_ws);
+  uint32_t* totals = reinterpret_cast<uint32_t*>(static_cast<char*>(d_ws) +
+                                                 align_up((size_t)nchunks * 256 * sizeof(uint32_t)));
   int passes = (nbits + 7) / 8;
   if (passes < 2) passes = 2;
   if (passes & 1) ++passes;  // an even number of passes leaves the result in (d_keys, d_vals)
@@ -139,10 +163,9 @@ int sort_pairs(uint64_t* d_keys, uint32_t* d_vals, uint64_t* d_keys_alt, uint32_
     const int shift = 8 * p;
     hipLaunchKernelGGL(radix_hist_kernel, dim3(nblocks), dim3(kSortBlock), 0, stream, ki, d_count,
                        shift, counts, nchunks);
-    hipLaunchKernelGGL(scan_exclusive_kernel, dim3(1), dim3(1024), 0, stream, counts,
-                       (int64_t)nchunks * 256);
+    hipLaunchKernelGGL(radix_scan_kernel, dim3(256), dim3(256), 0, stream, counts, totals, nchunks);
     hipLaunchKernelGGL(radix_scatter_kernel, dim3(nblocks), dim3(kSortBlock), 0, stream, ki, vi,
-                       ko, vo, d_count, shift, counts, nchunks);
+                       ko, vo, d_count, shift, counts, totals, nchunks);
     uint64_t* tk = ki; ki = ko; ko = tk;
     uint32_t* tv = vi; vi = vo; vo = tv;
   }
@@ -209,7 +232,7 @@ size_t unique_ws_bytes(int64_t n) {
   return b;
 }
 
-int unique_sorted(const uint64_t* d_keys, int64_t n, uint64_t* d_ukeys, int32_t* d_rep,
+int unique_sorted(const uint64_t* d_keys, int64_t n, int nbits, uint64_t* d_ukeys, int32_t* d_rep,
                   int32_t* d_inverse, int* d_count, void* d_ws, size_t ws_bytes,
                   hipStream_t stream) {
   M3D_HIP(hipMemsetAsync(d_count, 0, sizeof(int), stream));
@@ -232,7 +255,7 @@ int unique_sorted(const uint64_t* d_keys, int64_t n, uint64_t* d_ukeys, int32_t*
   const int bs = 256;
   hipLaunchKernelGGL(unique_insert_kernel, dim3((unsigned)cdiv(n, bs)), dim3(bs), 0, stream, d_keys,
                      n, tkeys, trep, cap - 1, pslot, d_ukeys, uslot, d_count);
-  int rc = sort_pairs(d_ukeys, uslot, kalt, valt, d_count, n, 64, sort_ws, sort_bytes, stream);
+  int rc = sort_pairs(d_ukeys, uslot, kalt, valt, d_count, n, nbits, sort_ws, sort_bytes, stream);
   if (rc != M3D_OK) return rc;
   hipLaunchKernelGGL(unique_rank_kernel, dim3((unsigned)cdiv(n, bs)), dim3(bs), 0, stream, uslot,
                      d_count, trep, d_rep);

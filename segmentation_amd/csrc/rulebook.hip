@@ -10,7 +10,6 @@
 
 namespace m3d {
 
-constexpr uint64_t kDropKey = 0xFFFFFFFFFFFFFFFEull;  // sorts after every real key
 
 struct Shape3 {
   int64_t s[3];
@@ -64,21 +63,24 @@ __global__ __launch_bounds__(256) void subm_probe_kernel(const int4* __restrict_
 }
 
 // ------------------------------------------------------------------------------ strided k2 s2
+// Rows whose parent falls outside the output shape get `drop_key` = one past the largest valid key.
 __global__ void strided_key_kernel(const int4* __restrict__ idx, int64_t n, Shape3 out_sh,
-                                   uint64_t* __restrict__ keys) {
+                                   uint64_t drop_key, uint64_t* __restrict__ keys) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const int4 c = idx[i];
   const int x = c.y >> 1, y = c.z >> 1, z = c.w >> 1;
   const bool ok = x < out_sh.s[0] && y < out_sh.s[1] && z < out_sh.s[2];
-  keys[i] = ok ? lin_key(c.x, x, y, z, out_sh) : kDropKey;
+  const uint64_t key = ok ? lin_key(c.x, x, y, z, out_sh) : drop_key;
+  keys[i] = key < drop_key ? key : drop_key;
 }
 
 __global__ void strided_count_kernel(const uint64_t* __restrict__ ukeys, const int* __restrict__ d_count,
-                                     int* __restrict__ d_nout, int64_t* __restrict__ n_out64) {
+                                     uint64_t drop_key, int* __restrict__ d_nout,
+                                     int64_t* __restrict__ n_out64) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   int m = *d_count;
-  if (m > 0 && ukeys[m - 1] == kDropKey) --m;
+  if (m > 0 && ukeys[m - 1] == drop_key) --m;
   *d_nout = m;
   *n_out64 = m;
 }
@@ -118,27 +120,29 @@ __device__ inline uint64_t spread3(uint64_t v) {  // 16 bits -> every third bit
   return v;
 }
 
+// mode 1: key = batch << (3*mb) | Morton(x, y, z) with mb bits per axis
+// mode 2: key = the row's first active kernel offset (rows are then grouped by offset; the sort is
+//         stable, so rows keep the order of `base` inside a group)
 __global__ void sched_key_kernel(const int32_t* __restrict__ pair, int kvol, int64_t ld, int64_t n,
-                                 const int4* __restrict__ idx, int mode, uint64_t* __restrict__ keys,
+                                 const int4* __restrict__ idx, int mode, int mb,
+                                 const int32_t* __restrict__ base, uint64_t* __restrict__ keys,
                                  uint32_t* __restrict__ vals) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n) return;
-  uint64_t key = 0;
-  if (idx) {
-    const int4 c = idx[t];
-    key = ((uint64_t)(c.x & 0xFFF) << 48) | (spread3((uint64_t)c.y) << 2) |
-          (spread3((uint64_t)c.z) << 1) | spread3((uint64_t)c.w);
+  const int32_t row = base ? base[t] : (int32_t)t;
+  uint64_t key;
+  if (mode == 1) {
+    const int4 c = idx[row];
+    const uint64_t m = (spread3((uint64_t)c.y) << 2) | (spread3((uint64_t)c.z) << 1) | spread3((uint64_t)c.w);
+    key = ((uint64_t)c.x << (3 * mb)) | (m & ((1ull << (3 * mb)) - 1));
   } else {
-    key = (uint64_t)t;
-  }
-  if (mode == 2) {
     int kk = kvol;  // rows without any pair go last
     for (int k = 0; k < kvol; ++k)
-      if (pair[(int64_t)k * ld + t] >= 0) { kk = k; break; }
-    key |= (uint64_t)(kk & 0xF) << 60;
+      if (pair[(int64_t)k * ld + row] >= 0) { kk = k; break; }
+    key = (uint64_t)kk;
   }
   keys[t] = key;
-  vals[t] = (uint32_t)t;
+  vals[t] = (uint32_t)row;
 }
 
 __global__ __launch_bounds__(256) void sched_gather_kernel(const int32_t* __restrict__ pair, int64_t ld,
@@ -228,7 +232,7 @@ extern "C" size_t m3d_strided_rulebook_workspace_bytes(int64_t n) {
 }
 
 extern "C" int m3d_strided_rulebook(const int32_t* d_indices, int64_t n, const int64_t spatial_shape[3],
-                                    int32_t* d_out_indices, int32_t* d_pair_fwd, int32_t* d_pair_bwd,
+                                    int batch_size, int32_t* d_out_indices, int32_t* d_pair_fwd, int32_t* d_pair_bwd,
                                     int64_t* d_n_out, void* d_ws, size_t ws_bytes, void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   M3D_CHECK_ARG(n > 0 && n < (int64_t)INT_MAX, "m3d_strided_rulebook: n out of range");
@@ -238,6 +242,11 @@ extern "C" int m3d_strided_rulebook(const int32_t* d_indices, int64_t n, const i
   Shape3 osh{{spatial_shape[0] / 2, spatial_shape[1] / 2, spatial_shape[2] / 2}};
   M3D_CHECK_ARG(osh.s[0] > 0 && osh.s[1] > 0 && osh.s[2] > 0,
                 "m3d_strided_rulebook: spatial shape too small for a stride-2 convolution");
+  M3D_CHECK_ARG(batch_size >= 1, "m3d_strided_rulebook: batch_size must be >= 1");
+  const long double vol = (long double)batch_size * osh.s[0] * osh.s[1] * osh.s[2];
+  M3D_CHECK_ARG(vol < 9.0e18L, "m3d_strided_rulebook: batch_size * output volume overflows 63 bits");
+  const uint64_t drop_key = (uint64_t)batch_size * (uint64_t)osh.s[0] * (uint64_t)osh.s[1] * (uint64_t)osh.s[2];
+  const int nbits = bits_for(drop_key);
   Arena a(d_ws, ws_bytes);
   uint64_t* keys = a.take<uint64_t>(n);
   uint64_t* ukeys = a.take<uint64_t>(n);
@@ -254,11 +263,11 @@ extern "C" int m3d_strided_rulebook(const int32_t* d_indices, int64_t n, const i
   const int bs = 256;
   const unsigned gb = (unsigned)cdiv(n, bs);
   const int4* idx = reinterpret_cast<const int4*>(d_indices);
-  hipLaunchKernelGGL(strided_key_kernel, dim3(gb), dim3(bs), 0, stream, idx, n, osh, keys);
+  hipLaunchKernelGGL(strided_key_kernel, dim3(gb), dim3(bs), 0, stream, idx, n, osh, drop_key, keys);
   M3D_LAUNCH_CHECK();
-  int rc = unique_sorted(keys, n, ukeys, rep, inverse, count, uws, ub, stream);
+  int rc = unique_sorted(keys, n, nbits, ukeys, rep, inverse, count, uws, ub, stream);
   if (rc != M3D_OK) return rc;
-  hipLaunchKernelGGL(strided_count_kernel, dim3(1), dim3(64), 0, stream, ukeys, count, nout, d_n_out);
+  hipLaunchKernelGGL(strided_count_kernel, dim3(1), dim3(64), 0, stream, ukeys, count, drop_key, nout, d_n_out);
   M3D_HIP(hipMemsetAsync(d_pair_fwd, 0xFF, (size_t)8 * n * sizeof(int32_t), stream));
   M3D_HIP(hipMemsetAsync(d_pair_bwd, 0xFF, (size_t)8 * n * sizeof(int32_t), stream));
   hipLaunchKernelGGL(strided_pair_kernel, dim3(gb), dim3(bs), 0, stream, idx, inverse, n, nout,
@@ -278,7 +287,9 @@ extern "C" size_t m3d_schedule_workspace_bytes(int64_t n) {
 }
 
 extern "C" int m3d_build_schedule(const int32_t* d_pair, int k, int64_t ld, int64_t n,
-                                  const int32_t* d_indices, int mode, int32_t* d_nbr,
+                                  const int32_t* d_indices, const int64_t* spatial_shape,
+                                  int batch_size, int mode, const int32_t* d_base_order,
+                                  int32_t* d_nbr,
                                   int32_t* d_out_row, uint32_t* d_tile_mask, void* d_ws,
                                   size_t ws_bytes, void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
@@ -302,14 +313,27 @@ extern "C" int m3d_build_schedule(const int32_t* d_pair, int k, int64_t ld, int6
       set_error("m3d_build_schedule: workspace too small (%zu given, %zu needed)", ws_bytes, a.off);
       return M3D_ENOSPC;
     }
+    int mb = 16, nbits = 4;
+    if (mode == 1) {
+      M3D_CHECK_ARG(d_indices != nullptr, "m3d_build_schedule: mode 1 needs the output coordinates");
+      if (spatial_shape) {
+        int64_t mx = spatial_shape[0];
+        if (spatial_shape[1] > mx) mx = spatial_shape[1];
+        if (spatial_shape[2] > mx) mx = spatial_shape[2];
+        mb = bits_for((uint64_t)(mx > 1 ? mx - 1 : 1));
+        if (mb > 16) mb = 16;
+      }
+      nbits = 3 * mb + bits_for((uint64_t)(batch_size > 1 ? batch_size - 1 : 1));
+    }
     hipLaunchKernelGGL(set_int_kernel, dim3(1), dim3(64), 0, stream, count, (int)n);
     hipLaunchKernelGGL(sched_key_kernel, dim3((unsigned)cdiv(n, bs)), dim3(bs), 0, stream, d_pair, k, ld,
-                       n, reinterpret_cast<const int4*>(d_indices), mode, keys, vals);
+                       n, reinterpret_cast<const int4*>(d_indices), mode, mb, d_base_order, keys, vals);
     M3D_LAUNCH_CHECK();
-    int rc = sort_pairs(keys, vals, kalt, valt, count, n, 64, sws, sb, stream);
+    int rc = sort_pairs(keys, vals, kalt, valt, count, n, nbits, sws, sb, stream);
     if (rc != M3D_OK) return rc;
     order = vals;
   }
+  if (mode == 0 && d_base_order) order = reinterpret_cast<const uint32_t*>(d_base_order);
   hipLaunchKernelGGL(sched_gather_kernel, dim3((unsigned)cdiv(npad, bs), k), dim3(bs), 0, stream, d_pair,
                      ld, n, npad, order, d_nbr, d_out_row);
   hipLaunchKernelGGL(sched_mask_kernel, dim3((unsigned)cdiv(npad, 256)), dim3(256), 0, stream, d_nbr, k,

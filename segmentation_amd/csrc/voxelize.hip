@@ -70,14 +70,24 @@ __global__ __launch_bounds__(256) void vox_minmax_kernel(const float* __restrict
     blo = min(blo, __shfl_xor(blo, s));
     bhi = max(bhi, __shfl_xor(bhi, s));
   }
+  __shared__ int red[4][8];
+  const int wave = threadIdx.x >> 6;
   if ((threadIdx.x & 63) == 0) {
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-      atomicMin(&mm[a], lo[a]);
-      atomicMax(&mm[3 + a], hi[a]);
+      red[wave][a] = lo[a];
+      red[wave][3 + a] = hi[a];
     }
-    atomicMin(&mm[6], blo);
-    atomicMax(&mm[7], bhi);
+    red[wave][6] = blo;
+    red[wave][7] = bhi;
+  }
+  __syncthreads();
+  if (threadIdx.x < 8) {
+    const int j = threadIdx.x;
+    const bool is_min = j < 3 || j == 6;
+    int v = red[0][j];
+    for (int w = 1; w < 4; ++w) v = is_min ? min(v, red[w][j]) : max(v, red[w][j]);
+    if (is_min) atomicMin(&mm[j], v); else atomicMax(&mm[j], v);
   }
 }
 
@@ -219,12 +229,12 @@ extern "C" int m3d_voxelize(const float* d_coord, const float* d_feat, const int
   const int bs = 256;
   const unsigned gb = (unsigned)cdiv(n, bs);
   hipLaunchKernelGGL(vox_init_kernel, dim3(1), dim3(64), 0, stream, w.mm);
-  hipLaunchKernelGGL(vox_minmax_kernel, dim3(gb < 2048 ? gb : 2048), dim3(bs), 0, stream, d_coord,
+  hipLaunchKernelGGL(vox_minmax_kernel, dim3(gb < 512 ? gb : 512), dim3(bs), 0, stream, d_coord,
                      d_offset, n, b, grid_size, inv_gs, grid_mode, w.mm);
   hipLaunchKernelGGL(vox_key_kernel, dim3(gb), dim3(bs), 0, stream, d_coord, d_offset, n, b,
                      grid_size, inv_gs, grid_mode, hash_method, w.mm, w.keys, w.bc, d_grid_coord);
   M3D_LAUNCH_CHECK();
-  int rc = unique_sorted(w.keys, n, ukeys, w.rep, w.inverse, w.count, w.uniq, w.uniq_bytes, stream);
+  int rc = unique_sorted(w.keys, n, 64, ukeys, w.rep, w.inverse, w.count, w.uniq, w.uniq_bytes, stream);
   if (rc != M3D_OK) return rc;
   M3D_HIP(hipMemsetAsync(w.sums, 0, (size_t)n * c * sizeof(double), stream));
   M3D_HIP(hipMemsetAsync(w.cnt, 0, (size_t)n * sizeof(int32_t), stream));

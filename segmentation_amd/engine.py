@@ -121,21 +121,23 @@ class SpUNetEngine:
         self.text_folded = _Conv(wfold.contiguous(), None, bfold.contiguous())
 
     # ------------------------------------------------------------------ kernel maps
-    def build_levels(self, voxel_coords, spatial_shape):
+    def build_levels(self, voxel_coords, spatial_shape, batch_size=1):
+        """Kernel maps + tile schedules of every resolution level.  Level 0 rows arrive in hash order and
+        are walked in Morton order; deeper levels are already in row-major spatial order."""
         levels = []
         idx, shape = voxel_coords, list(spatial_shape)
         for l in range(self.num_stages + 1):
             lv = _Level()
             lv.indices, lv.shape, lv.n = idx, shape, idx.shape[0]
             lv.pair_subm = ops.subm_rulebook(idx, shape)
-            lv.subm = ops.build_schedule(lv.pair_subm, lv.n, idx, 1)
+            lv.subm = ops.build_schedule(lv.pair_subm, lv.n, idx, 1 if l == 0 else 0, shape, batch_size)
             lv.down = lv.up = lv.pair_fwd = lv.pair_bwd = None
             levels.append(lv)
             if l < self.num_stages:
-                oi, oshape, pf, pb = ops.strided_rulebook(idx, shape)
+                oi, oshape, pf, pb = ops.strided_rulebook(idx, shape, batch_size)
                 lv.pair_fwd, lv.pair_bwd = pf, pb
                 lv.down = ops.build_schedule(pf, oi.shape[0], None, 0)
-                lv.up = ops.build_schedule(pb, lv.n, idx, 2)
+                lv.up = ops.build_schedule(pb, lv.n, None, 2, base_order=lv.subm.out_row)
                 idx, shape = oi, oshape
         return levels
 
@@ -186,7 +188,7 @@ class SpUNetEngine:
     def forward_features(self, coord, feat, offset, grid_size, keep=None):
         """Whole path up to the per-voxel open-vocabulary features.  Returns (features [N0, D], vox dict)."""
         vox = ops.voxelize(coord, feat, offset, grid_size, pad=128)
-        levels = self.build_levels(vox["voxel_coords"], vox["spatial_shape"])
+        levels = self.build_levels(vox["voxel_coords"], vox["spatial_shape"], vox["batch_size"])
         x = self.backbone(vox["voxel_feats"], levels, keep)
         f = self.final
         out = ops.conv_fwd(x, f.w, None, x.shape[0], shift=f.shift)
@@ -203,14 +205,14 @@ class SpUNetEngine:
             raise RuntimeError("call set_text_embeddings() first")
         if fold_head:
             vox = ops.voxelize(coord, feat, offset, grid_size, pad=128)
-            levels = self.build_levels(vox["voxel_coords"], vox["spatial_shape"])
+            levels = self.build_levels(vox["voxel_coords"], vox["spatial_shape"], vox["batch_size"])
             x = self.backbone(vox["voxel_feats"], levels)
             t = self.text_folded
-            logits = ops.conv_fwd(x, t.w, None, x.shape[0], shift=t.shift)
+            logits = ops.conv_fwd(x, t.w, None, x.shape[0], shift=t.shift, flop_cout=self.n_classes)
             self.last_stats = dict(n_points=int(coord.shape[0]), n_voxels=[lv.n for lv in levels])
         else:
             feats, vox = self.forward_features(coord, feat, offset, grid_size)
-            logits = ops.conv_fwd(feats, self.text.w, None, feats.shape[0])
+            logits = ops.conv_fwd(feats, self.text.w, None, feats.shape[0], flop_cout=self.n_classes)
         vlabel = ops.argmax_rows(logits, self.n_classes)
         plabel = ops.gather_labels(vlabel, vox["v2p_map"])
         out = dict(pred=plabel, voxel_pred=vlabel, v2p_map=vox["v2p_map"], n_voxels=vox["n_voxels"])

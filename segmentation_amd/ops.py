@@ -15,6 +15,10 @@ GRID = {"div": 0, "recip": 1, "floor": 2}
 
 _workspaces = {}
 
+# When set to a list, conv_fwd appends (kind, algorithmic_flops, start_event, end_event) per launch;
+# used by bench.py to time the convolution kernel with HIP events on the launch stream.
+PROFILE = None
+
 
 def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -119,7 +123,7 @@ def subm_rulebook(indices, spatial_shape):
     return pair
 
 
-def strided_rulebook(indices, spatial_shape):
+def strided_rulebook(indices, spatial_shape, batch_size):
     """k2 s2 p0 kernel map (v1m3:154-161).  Returns out_indices [M,4], out_shape, pair_fwd [8,M]
     (a strided view), pair_bwd [8,N]."""
     lib = _lib.load()
@@ -135,7 +139,7 @@ def strided_rulebook(indices, spatial_shape):
     pb = torch.empty((8, n), dtype=torch.int32, device=dev)
     nout = torch.empty((1,), dtype=torch.int64, device=dev)
     ws = _workspace(lib.m3d_strided_rulebook_workspace_bytes(n), dev)
-    rc = lib.m3d_strided_rulebook(_ptr(indices), n, _shape3(spatial_shape), _ptr(out_idx), _ptr(pf),
+    rc = lib.m3d_strided_rulebook(_ptr(indices), n, _shape3(spatial_shape), int(batch_size), _ptr(out_idx), _ptr(pf),
                                   _ptr(pb), _ptr(nout), _ptr(ws), ws.numel(), _stream())
     _lib.check(rc, "m3d_strided_rulebook")
     m = int(nout.item())
@@ -154,7 +158,7 @@ class Schedule:
     k: int
 
 
-def build_schedule(pair, n, indices=None, mode=0):
+def build_schedule(pair, n, indices=None, mode=0, spatial_shape=None, batch_size=1, base_order=None):
     lib = _lib.load()
     _need_cuda(pair)
     assert pair.dtype == torch.int32 and pair.dim() == 2
@@ -170,8 +174,12 @@ def build_schedule(pair, n, indices=None, mode=0):
         indices = indices.contiguous()
         assert indices.dtype == torch.int32 and indices.shape == (n, 4)
     ws = _workspace(lib.m3d_schedule_workspace_bytes(n), dev)
-    rc = lib.m3d_build_schedule(_ptr(pair), k, ld, n, _ptr(indices), int(mode), _ptr(nbr), _ptr(out_row),
-                                _ptr(mask), _ptr(ws), ws.numel(), _stream())
+    if base_order is not None:
+        assert base_order.dtype == torch.int32 and base_order.is_contiguous() and base_order.numel() >= n
+    shp = _shape3(spatial_shape) if spatial_shape is not None else None
+    rc = lib.m3d_build_schedule(_ptr(pair), k, ld, n, _ptr(indices), shp, int(batch_size), int(mode),
+                                _ptr(base_order), _ptr(nbr), _ptr(out_row), _ptr(mask), _ptr(ws), ws.numel(),
+                                _stream())
     _lib.check(rc, "m3d_build_schedule")
     return Schedule(nbr, out_row, mask, n, npad, k)
 
@@ -184,7 +192,7 @@ def pack_weight(weight):
 
 
 def conv_fwd(in0, weight_packed, sched: Optional[Schedule], n_out, in1=None, scale=None, shift=None,
-             residual=None, relu=False, out=None):
+             residual=None, relu=False, out=None, flop_cout=None):
     """out[row] = act(scale * sum_k W[k] . cat(in0, in1)[nbr[k][t]] + shift + residual[row]).
 
     sched=None is the dense 1x1 case (Custom1x1Subm3d, structure.py:336-347)."""
@@ -223,11 +231,26 @@ def conv_fwd(in0, weight_packed, sched: Optional[Schedule], n_out, in1=None, sca
             raise ValueError(f"schedule covers {sched.n} rows, output has {n_out}")
         nbr, orow, mask, npad = sched.nbr, sched.out_row, sched.tile_mask, sched.npad
     ws = _workspace(lib.m3d_conv_workspace_bytes(n_out, cout, k), dev)
+    prof = PROFILE
+    if prof is not None:
+        if sched is None:
+            npairs = n_out
+        else:
+            if getattr(sched, "_npairs", None) is None:
+                sched._npairs = int((sched.nbr >= 0).sum().item())
+            npairs = sched._npairs
+        mfma = c0 % 32 == 0 and c1 % 32 == 0 and cout % 32 == 0
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
     rc = lib.m3d_conv_fwd_f32(_ptr(in0), c0, _ptr(in1), c1, _ptr(weight_packed), k, cout, _ptr(nbr),
                               _ptr(orow), _ptr(mask), n_out, npad, _ptr(scale), _ptr(shift),
                               _ptr(residual), int(bool(relu)), _ptr(out), ldo, _ptr(ws), ws.numel(),
                               _stream())
     _lib.check(rc, "m3d_conv_fwd_f32")
+    if prof is not None:
+        ev1.record()
+        prof.append(("igemm" if mfma else "direct", 2.0 * npairs * cin * (flop_cout or cout), ev0, ev1,
+                     (n_out, cin, cout, k)))
     return out
 
 

@@ -35,7 +35,7 @@ class ImplicitGemmIndiceData:
     once per map, and shared by every convolution that uses the key."""
 
     def __init__(self, *, pair_fwd, pair_bwd, out_indices, indices, out_spatial_shape, spatial_shape,
-                 ksize, stride, padding, dilation, is_subm, algo=ConvAlgo.MaskImplicitGemm):
+                 ksize, stride, padding, dilation, is_subm, batch_size=1, algo=ConvAlgo.MaskImplicitGemm):
         self.pair_fwd = pair_fwd
         self.pair_bwd = pair_bwd
         self.out_indices = out_indices
@@ -44,6 +44,7 @@ class ImplicitGemmIndiceData:
         self.spatial_shape = list(spatial_shape)
         self.ksize, self.stride, self.padding, self.dilation = ksize, stride, padding, dilation
         self.is_subm = is_subm
+        self.batch_size = batch_size
         self.algo = algo
         self._sched_fwd = None
         self._sched_bwd = None
@@ -55,7 +56,8 @@ class ImplicitGemmIndiceData:
             # submanifold maps walk the voxels in Morton order; strided outputs are already in
             # row-major spatial order
             mode = 1 if self.is_subm else 0
-            self._sched_fwd = ops.build_schedule(self.pair_fwd, n_out, self.out_indices if mode else None, mode)
+            self._sched_fwd = ops.build_schedule(self.pair_fwd, n_out, self.out_indices if mode else None, mode,
+                                                 self.out_spatial_shape, self.batch_size)
         return self._sched_fwd
 
     @property
@@ -63,7 +65,9 @@ class ImplicitGemmIndiceData:
         if self._sched_bwd is None:
             if self.pair_bwd is None:
                 raise RuntimeError("submanifold kernel maps have no inverse schedule")
-            self._sched_bwd = ops.build_schedule(self.pair_bwd, self.indices.shape[0], self.indices, 2)
+            n = self.indices.shape[0]
+            morton = ops.build_schedule(self.pair_bwd, n, self.indices, 1, self.spatial_shape, self.batch_size)
+            self._sched_bwd = ops.build_schedule(self.pair_bwd, n, None, 2, base_order=morton.out_row)
         return self._sched_bwd
 
 
@@ -207,16 +211,16 @@ class SparseConvolution(SparseModule):
             data = ImplicitGemmIndiceData(pair_fwd=pair, pair_bwd=None, out_indices=x.indices, indices=x.indices,
                                           out_spatial_shape=x.spatial_shape, spatial_shape=x.spatial_shape,
                                           ksize=self.kernel_size, stride=self.stride, padding=self.padding,
-                                          dilation=self.dilation, is_subm=True)
+                                          dilation=self.dilation, is_subm=True, batch_size=x.batch_size)
         else:
             if (self.kernel_size != [2, 2, 2] or self.stride != [2, 2, 2] or self.padding != [0, 0, 0]
                     or self.dilation != [1, 1, 1]):
                 raise NotImplementedError("SparseConv3d supports kernel_size 2, stride 2, padding 0")
-            oi, oshape, pf, pb = ops.strided_rulebook(x.indices, x.spatial_shape)
+            oi, oshape, pf, pb = ops.strided_rulebook(x.indices, x.spatial_shape, x.batch_size)
             data = ImplicitGemmIndiceData(pair_fwd=pf, pair_bwd=pb, out_indices=oi, indices=x.indices,
                                           out_spatial_shape=oshape, spatial_shape=x.spatial_shape,
                                           ksize=self.kernel_size, stride=self.stride, padding=self.padding,
-                                          dilation=self.dilation, is_subm=False)
+                                          dilation=self.dilation, is_subm=False, batch_size=x.batch_size)
         if self.indice_key is not None:
             x.indice_dict[self.indice_key] = data
         return data

@@ -22,11 +22,11 @@ def level(device):
     sp = oracle.sparsify(sc["coord"], sc["feat"], off, 0.02)
     idx = torch.from_numpy(sp["voxel_coords"]).to(device)
     pair = ops.subm_rulebook(idx, sp["spatial_shape"])
-    sched = ops.build_schedule(pair, idx.shape[0], idx, 1)
-    oi, oshape, pf, pb = ops.strided_rulebook(idx, sp["spatial_shape"])
+    sched = ops.build_schedule(pair, idx.shape[0], idx, 1, sp["spatial_shape"], 1)
+    oi, oshape, pf, pb = ops.strided_rulebook(idx, sp["spatial_shape"], 1)
     return dict(sp=sp, idx=idx, pair=pair.cpu().numpy(), sched=sched, oi=oi, pf=pf, pb=pb,
                 sched_down=ops.build_schedule(pf, oi.shape[0], None, 0),
-                sched_up=ops.build_schedule(pb, idx.shape[0], idx, 2))
+                sched_up=ops.build_schedule(pb, idx.shape[0], None, 2, base_order=sched.out_row))
 
 
 # (cin, cout): every SubM shape of spunet34c plus odd shapes for the direct kernel
@@ -92,7 +92,7 @@ def test_all_tile_configurations(device, target):
     idx = torch.from_numpy(sp["voxel_coords"]).to(device)
     n = idx.shape[0]
     pair = ops.subm_rulebook(idx, sp["spatial_shape"])
-    sched = ops.build_schedule(pair, n, idx, 1)
+    sched = ops.build_schedule(pair, n, idx, 1, sp["spatial_shape"], 1)
     for cin, cout in [(32, 32), (64, 64), (96, 96), (128, 128), (256, 256)]:
         g = torch.Generator().manual_seed(cin)
         x = torch.randn(n, cin, generator=g)

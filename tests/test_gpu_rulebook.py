@@ -41,7 +41,7 @@ def test_strided_rulebook_chain_bit_exact(device, seed, target, batch):
     idx_ref, shape = sp["voxel_coords"], sp["spatial_shape"]
     idx = torch.from_numpy(idx_ref).to(device)
     for level in range(4):
-        oi, oshape, pf, pb = ops.strided_rulebook(idx, shape)
+        oi, oshape, pf, pb = ops.strided_rulebook(idx, shape, sp["batch_size"])
         roi, roshape, rpf, rpb = oracle.strided_rulebook(idx_ref, shape)
         assert oshape == roshape
         assert np.array_equal(oi.cpu().numpy(), roi)
@@ -52,7 +52,7 @@ def test_strided_rulebook_chain_bit_exact(device, seed, target, batch):
 
 def test_strided_rulebook_drops_rows_outside_the_output_shape(device):
     idx = np.array([[0, 4, 0, 0], [0, 0, 0, 0], [0, 1, 1, 1], [0, 2, 3, 2]], dtype=np.int32)  # shape 5 -> out 2
-    oi, oshape, pf, pb = ops.strided_rulebook(torch.from_numpy(idx).to(device), [5, 5, 5])
+    oi, oshape, pf, pb = ops.strided_rulebook(torch.from_numpy(idx).to(device), [5, 5, 5], 1)
     roi, roshape, rpf, rpb = oracle.strided_rulebook(idx, [5, 5, 5])
     assert np.array_equal(oi.cpu().numpy(), roi) and np.array_equal(pf.cpu().numpy(), rpf)
     assert np.array_equal(pb.cpu().numpy(), rpb)
@@ -64,10 +64,12 @@ def test_schedule_is_a_permutation_of_the_kernel_map(device, mode):
     idx = torch.from_numpy(sp["voxel_coords"]).to(device)
     n = idx.shape[0]
     if mode == 2:
-        _, _, _, pair = ops.strided_rulebook(idx, sp["spatial_shape"])
+        _, _, _, pair = ops.strided_rulebook(idx, sp["spatial_shape"], 1)
+        base = ops.build_schedule(pair, n, idx, 1, sp["spatial_shape"], 1).out_row
+        sched = ops.build_schedule(pair, n, None, 2, base_order=base)
     else:
         pair = ops.subm_rulebook(idx, sp["spatial_shape"])
-    sched = ops.build_schedule(pair, n, idx if mode else None, mode)
+        sched = ops.build_schedule(pair, n, idx if mode else None, mode, sp["spatial_shape"], 1)
     torch.cuda.synchronize()
     orow = sched.out_row.cpu().numpy()
     nbr = sched.nbr.cpu().numpy()
@@ -81,6 +83,14 @@ def test_schedule_is_a_permutation_of_the_kernel_map(device, mode):
     for k in range(nbr.shape[0]):
         ref_mask |= (valid[k].astype(np.uint32) << np.uint32(k))
     assert np.array_equal(mask, ref_mask)
-    if mode == 2:  # rows grouped by their single active kernel offset
+    if mode == 2:  # rows grouped by their single active kernel offset, Morton order kept inside a group
         kk = np.argmax(p[:, orow[:n]] >= 0, axis=0)
         assert (np.diff(kk) >= 0).all()
+        pos = np.empty(n, dtype=np.int64)
+        pos[base.cpu().numpy()[:n]] = np.arange(n)
+        for k in range(8):
+            assert (np.diff(pos[orow[:n][kk == k]]) > 0).all()
+    if mode == 1:  # Morton order: keys non-decreasing
+        from tools.mask_study_helpers import morton_key
+        mk = morton_key(sp["voxel_coords"][orow[:n]])
+        assert (np.diff(mk.astype(np.float64)) >= 0).all()
