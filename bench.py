@@ -28,7 +28,7 @@ N_CLASSES = 200
 TARGET_VOXELS = 290_000        # scene-generator target; lands at ~250 k occupied 2 cm voxels
 
 
-def build_engine(device):
+def build_engine(device, precision="f32"):
     from segmentation_amd import spunet
     from segmentation_amd.engine import SpUNetEngine
     from segmentation_amd import scenes
@@ -37,7 +37,7 @@ def build_engine(device):
     model = spunet.PPT(spunet.SpUNet(**{k: cfg[k] for k in ("in_channels", "out_channels", "base_channels",
                                                              "context_channels", "channels", "layers",
                                                              "conditions")}), cfg["conditions"], 256).eval()
-    eng = SpUNetEngine(model, cfg, "ScanNet", device)
+    eng = SpUNetEngine(model, cfg, "ScanNet", device, precision=precision)
     eng.set_text_embeddings(torch.from_numpy(scenes.text_embeddings(N_CLASSES, cfg["out_channels"], seed=1)))
     return eng, model, cfg
 
@@ -70,6 +70,7 @@ def main():
     ap.add_argument("--target-voxels", type=int, default=TARGET_VOXELS)
     ap.add_argument("--scenes-per-rank", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precision", default="f32", choices=["f32", "bf16x6", "bf16x3"])
     ap.add_argument("--fold-head", action="store_true", help="fold `final` into the text matrix (not the headline)")
     args = ap.parse_args()
 
@@ -87,7 +88,7 @@ def main():
         dist.init_process_group("nccl", device_id=device)
 
     from segmentation_amd import ops, scenes
-    eng, model, cfg = build_engine(device)
+    eng, model, cfg = build_engine(device, args.precision)
 
     # scene i of the job goes to rank i mod world (weak scaling: scenes_per_rank scenes on every GPU)
     my = []
@@ -130,14 +131,8 @@ def main():
         torch.cuda.synchronize()
         prof, ops.PROFILE = ops.PROFILE, None
 
-    tot = torch.tensor([elapsed, float(nvox)], dtype=torch.float64, device=device)
-    if dist is not None:
-        tmax = tot.clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-        elapsed, nvox_all = float(tmax[0]), float(tot[1])
-    else:
-        nvox_all = float(nvox)
+    from segmentation_amd import sharding
+    elapsed, nvox_all = sharding.reduce_job(elapsed, float(nvox), dist, device)
 
     if rank == 0:
         ig = [(f, e0.elapsed_time(e1) * 1e-3) for kind, f, e0, e1, _ in prof if kind == "igemm"]
@@ -166,7 +161,8 @@ def main():
                                          "fp32 + 768-d CLIP-text argmax (C=200), voxelize+kernel maps included",
                                 scenes_per_gpu=args.scenes_per_rank, voxels_per_scene=st.get("n_voxels", [0])[0],
                                 points_per_scene=st.get("n_points", 0), level_voxels=st.get("n_voxels"),
-                                parallelism=f"scene-sharded x{world}, no collectives", fold_head=args.fold_head),
+                                parallelism=f"scene-sharded x{world}, no collectives", fold_head=args.fold_head,
+                                precision=args.precision),
                     roofline=roofline, cpu_baseline=cb)
         print(json.dumps(line), flush=True)
     if dist is not None:

@@ -32,6 +32,10 @@ extern "C" {
 #define M3D_ENOSPC (-2)   /* workspace too small */
 #define M3D_EHIP (-3)     /* a HIP runtime call or kernel launch failed */
 
+#define M3D_PREC_F32 0     /* exact f32 products on v_mfma_f32_32x32x2_f32 */
+#define M3D_PREC_BF16X3 1  /* f32 operands split in 2 bf16 terms, 3 bf16 MFMA products (~2^-17 per product) */
+#define M3D_PREC_BF16X6 2  /* f32 operands split in 3 bf16 terms, 6 bf16 MFMA products (~2^-24 per product) */
+
 #define M3D_HASH_FNV 0
 #define M3D_HASH_RAVEL 1
 #define M3D_GRID_DIV 0    /* trunc(coord / grid_size): torch CPU kernel */
@@ -115,7 +119,8 @@ int m3d_build_schedule(const int32_t* d_pair, int k, int64_t ld, int64_t n,
                        uint32_t* d_tile_mask, void* d_ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
- * Sparse convolution forward, fp32, implicit GEMM on v_mfma_f32_32x32x2_f32.
+ * Sparse convolution forward, f32 in / f32 out, implicit GEMM on the matrix cores.  `precision`
+ * selects how the f32 products are formed (M3D_PREC_*); accumulation is always f32.
  * Replaces the feature arithmetic of spconv.SubMConv3d / SparseConv3d / SparseInverseConv3d
  * (call sites above) and Custom1x1Subm3d's torch.mm (structure.py:336-347), with the
  * eval-mode PDBatchNorm affine, residual add and ReLU of BasicBlock.forward
@@ -125,7 +130,8 @@ int m3d_build_schedule(const int32_t* d_pair, int k, int64_t ld, int64_t n,
  *
  *   d_in0 [*,c0], d_in1 [*,c1] (d_in1 may be NULL, c1 = 0): the two K-slabs of a concatenated
  *        input (spconv_unet_v1m3_pdnorm.py:404) read without materialising the concat
- *   d_weight [k,cout,c0+c1] f32: reference layout [Cout,k0,k1,k2,Cin] permuted to offset-major
+ *   d_weight: the reference's [Cout,k0,k1,k2,Cin] f32 weight converted by m3d_conv_pack_weight for
+ *        the same `precision` ([k,cout,cin] f32, or pre-split bf16 terms)
  *   d_nbr/d_out_row/d_tile_mask: from m3d_build_schedule; all three NULL = dense 1x1 (k = 1)
  *   d_scale/d_shift [cout] may be NULL (1 / 0); d_residual [n_out_rows,cout] may be NULL
  *   d_out [n_out_rows, ldo] (ldo >= cout, row stride in floats)
@@ -136,8 +142,14 @@ int m3d_conv_fwd_f32(const float* d_in0, int c0, const float* d_in1, int c1,
                      const float* d_weight, int k, int cout, const int32_t* d_nbr,
                      const int32_t* d_out_row, const uint32_t* d_tile_mask, int64_t n,
                      int64_t npad, const float* d_scale, const float* d_shift,
-                     const float* d_residual, int relu, float* d_out, int64_t ldo, void* d_ws,
-                     size_t ws_bytes, void* stream);
+                     const float* d_residual, int relu, float* d_out, int64_t ldo, int precision,
+                     void* d_ws, size_t ws_bytes, void* stream);
+
+/* Weight conversion for m3d_conv_fwd_f32: d_weight_ref is the reference layout [cout, k, cin] f32
+ * (spconv's [Cout, k0, k1, k2, Cin] flattened; structure.py:338 relies on it for k = 1). */
+size_t m3d_conv_packed_weight_bytes(int cout, int k, int cin, int precision);
+int m3d_conv_pack_weight(const float* d_weight_ref, int cout, int k, int cin, int precision,
+                         void* d_out, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Open-vocabulary head.  Replaces clip_feat = features[v2p_map]

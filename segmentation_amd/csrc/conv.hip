@@ -20,6 +20,8 @@
 // line), weights [k][Cout][Cin] so that a weight slab is also 128 B per output channel.
 #include "common.h"
 
+#include <stdlib.h>
+
 namespace m3d {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
@@ -38,7 +40,86 @@ struct ConvArgs {
   float* slab;  // split-K partial sums [z][npad][cout], or nullptr
   int64_t n, npad, ldo;
   int c0, c1, cout, kvol, relu;
+  int dbg;  // timing-only ablation bits (M3D_DBG); 0 in normal operation
 };
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+// Accumulator register r of a 32x32 tile is row (r&3) + 8*(r>>2) + 4*(lane>>5), column lane&31.
+template <int NT>
+__device__ inline void conv_epilogue(const ConvArgs& a, const floatx16 (&acc)[NT], const int* orow_s,
+                                     int64_t tile_base, int col_base, int wm, int wn, int lane) {
+  const int h = lane >> 5, cl = lane & 31;
+  if (a.slab) {
+    float* dst = a.slab + ((int64_t)blockIdx.z * a.npad + tile_base + wm * 32) * a.cout + col_base;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int col = (wn * NT + nt) * 32 + cl;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rl = (r & 3) + 8 * (r >> 2) + 4 * h;
+        dst[(int64_t)rl * a.cout + col] = acc[nt][r];
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int col = col_base + (wn * NT + nt) * 32 + cl;
+    const float sc = a.scale ? a.scale[col] : 1.f;
+    const float sh = a.shift ? a.shift[col] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int rl = (r & 3) + 8 * (r >> 2) + 4 * h;
+      const int orow = orow_s[wm * 32 + rl];
+      if (orow >= 0) {
+        float v = acc[nt][r] * sc + sh;
+        if (a.residual) v += a.residual[(int64_t)orow * a.cout + col];
+        if (a.relu) v = fmaxf(v, 0.f);
+        a.out[(int64_t)orow * a.ldo + col] = v;
+      }
+    }
+  }
+}
+
+// Workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8 share an L2).  Map block ids so
+// that each XCD walks a contiguous range of the (spatially sorted) tile schedule: neighbouring tiles
+// gather overlapping input rows, which then hit in that XCD's L2.  Bijective for any tile count.
+__device__ inline int64_t xcd_tile(unsigned bid, unsigned ntiles) {
+  const unsigned xcd = bid & 7u, q = ntiles >> 3, r = ntiles & 7u;
+  const unsigned base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return (int64_t)base + (bid >> 3);
+}
+
+// Active kernel offsets of a workgroup (bmask) and of one of its 32-row waves (wmask); with
+// gridDim.z > 1 the offsets are dealt round-robin over z.
+template <int WM>
+__device__ inline void conv_masks(const ConvArgs& a, int64_t tile_base, int wm, uint32_t& bmask,
+                                  uint32_t& wmask) {
+  bmask = 0;
+  wmask = 0;
+  if (a.tile_mask) {
+#pragma unroll
+    for (int w = 0; w < WM; ++w) {
+      const uint32_t m = a.tile_mask[tile_base / 32 + w];
+      bmask |= m;
+      if (w == wm) wmask = m;
+    }
+  } else {
+    bmask = wmask = 1u;
+  }
+  if (gridDim.z > 1) {
+    uint32_t keep = 0;
+    int ord = 0;
+    for (uint32_t m = bmask; m; m &= m - 1, ++ord)
+      if (ord % (int)gridDim.z == (int)blockIdx.z) keep |= m & (0u - m);
+    bmask = keep;
+    wmask &= keep;
+  }
+  bmask = __builtin_amdgcn_readfirstlane(bmask);
+  wmask = __builtin_amdgcn_readfirstlane(wmask);
+}
 
 constexpr int kBK = 32;
 constexpr int kLdr = 36;  // LDS row stride in floats
@@ -55,33 +136,13 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_f32_kernel(ConvArgs a
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
-  const int64_t tile_base = (int64_t)blockIdx.x * BM;
+  const int64_t tile_base = xcd_tile(blockIdx.x, gridDim.x) * BM;
   const int col_base = blockIdx.y * BN;
   const int cin = a.c0 + a.c1;
   const int nchunk = cin / kBK;
 
-  // active kernel offsets of this workgroup / of this wave
-  uint32_t bmask = 0, wmask = 0;
-  if (a.tile_mask) {
-#pragma unroll
-    for (int w = 0; w < WM; ++w) {
-      const uint32_t m = a.tile_mask[tile_base / 32 + w];
-      bmask |= m;
-      if (w == wm) wmask = m;
-    }
-  } else {
-    bmask = wmask = 1u;
-  }
-  if (gridDim.z > 1) {  // split the kernel offsets round-robin over z
-    uint32_t keep = 0;
-    int ord = 0;
-    for (uint32_t m = bmask; m; m &= m - 1, ++ord)
-      if (ord % (int)gridDim.z == (int)blockIdx.z) keep |= m & (0u - m);
-    bmask = keep;
-    wmask &= keep;
-  }
-  bmask = __builtin_amdgcn_readfirstlane(bmask);
-  wmask = __builtin_amdgcn_readfirstlane(wmask);
+  uint32_t bmask, wmask;
+  conv_masks<WM>(a, tile_base, wm, bmask, wmask);
 
   for (int r = tid; r < BM; r += NTHR) {
     const int64_t t = tile_base + r;
@@ -203,37 +264,207 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_f32_kernel(ConvArgs a
     __syncthreads();
   }
 
-  // epilogue: accumulator register r of a 32x32 tile is row (r&3) + 8*(r>>2) + 4*(lane>>5), column lane&31
-  const int h = lane >> 5, cl = lane & 31;
-  if (a.slab) {
-    float* dst = a.slab + ((int64_t)blockIdx.z * a.npad + tile_base + wm * 32) * a.cout + col_base;
+  conv_epilogue<NT>(a, acc, orow_s, tile_base, col_base, wm, wn, lane);
+}
+
+// ------------------------------------------------------------------------------------------
+// Split-bf16 variant: every f32 multiplicand is split into T bf16 terms (x = x0 + x1 (+ x2), each
+// term the bf16 rounding of the remainder) and the product is formed from the leading cross terms
+// on the bf16 matrix instruction v_mfma_f32_32x32x16_bf16 with f32 accumulation:
+//   T = 2: x0*w0 + x0*w1 + x1*w0                       (relative error ~2^-17 per product)
+//   T = 3: + x1*w1 + x0*w2 + x2*w0                     (relative error ~2^-24, i.e. f32 level)
+// bf16 products are exact in f32, so only the dropped cross terms and the accumulation round.
+// The bf16 pipe is 16x the f32 matrix rate per k, so 3 (6) products cost 3/16 (6/16) of the exact
+// kernel's matrix time.  Weights arrive pre-split ([k][Cout][Cin/32][T][32] bf16); activations are
+// gathered as f32 and split while they are committed to LDS.
+constexpr int kRowB = 80;  // LDS bytes per row and term: 32 bf16 + 16 B pad (conflict-free b128 reads)
+
+template <int WM, int WN, int NT, int T>
+__global__ __launch_bounds__(64 * WM * WN) void conv_igemm_split_kernel(ConvArgs a) {
+  constexpr int BM = 32 * WM, BN = 32 * NT * WN, NTHR = 64 * WM * WN;
+  constexpr int A_V = (BM * 8 + NTHR - 1) / NTHR;       // float4 per thread, A slab
+  constexpr int W_E = BN * T * 4;                        // 16-B pieces of the W slab
+  constexpr int W_V = (W_E + NTHR - 1) / NTHR;
+  constexpr int A_PLANE = BM * kRowB, W_PLANE = BN * kRowB;
+  constexpr int BUF = T * (A_PLANE + W_PLANE);
+  extern __shared__ __align__(16) char ldsb[];
+  int* orow_s = reinterpret_cast<int*>(ldsb + 2 * BUF);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int64_t tile_base = xcd_tile(blockIdx.x, gridDim.x) * BM;
+  const int col_base = blockIdx.y * BN;
+  const int cin = a.c0 + a.c1;
+  const int nchunk = cin / kBK;
+  const char* wsplit = reinterpret_cast<const char*>(a.weight);
+
+  uint32_t bmask, wmask;
+  conv_masks<WM>(a, tile_base, wm, bmask, wmask);
+
+  for (int r = tid; r < BM; r += NTHR) {
+    const int64_t t = tile_base + r;
+    orow_s[r] = a.out_row ? a.out_row[t] : (t < a.n ? (int)t : -1);
+  }
+
+  floatx16 acc[NT];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const int col = (wn * NT + nt) * 32 + cl;
+  for (int i = 0; i < NT; ++i)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int rl = (r & 3) + 8 * (r >> 2) + 4 * h;
-        dst[(int64_t)rl * a.cout + col] = acc[nt][r];
+    for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
+
+  const int nstage = __popc(bmask) * nchunk;
+  float4 ra[A_V];
+  uint4 rw[W_V];
+  int ridx[A_V];
+
+  auto load_idx = [&](int k) {
+#pragma unroll
+    for (int v = 0; v < A_V; ++v) {
+      const int e = tid + v * NTHR;
+      int id = -1;
+      if (e < BM * 8) {
+        const int64_t t = tile_base + (e >> 3);
+        id = a.nbr ? a.nbr[(int64_t)k * a.npad + t] : (t < a.n ? (int)t : -1);
+      }
+      ridx[v] = id;
+    }
+  };
+  auto issue = [&](int k, int cc) {
+    const float* src;
+    int ld, col;
+    if (cc * kBK < a.c0) { src = a.in0; ld = a.c0; col = cc * kBK; }
+    else { src = a.in1; ld = a.c1; col = cc * kBK - a.c0; }
+#pragma unroll
+    for (int v = 0; v < A_V; ++v) {
+      const int e = tid + v * NTHR;
+      float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ridx[v] >= 0 && !(a.dbg & 2))
+        x = *reinterpret_cast<const float4*>(src + (int64_t)ridx[v] * ld + col + (e & 7) * 4);
+      ra[v] = x;
+    }
+#pragma unroll
+    for (int v = 0; v < W_V; ++v) {
+      const int e = tid + v * NTHR;
+      const int j = e / (T * 4), p = e % (T * 4);
+      uint4 x = make_uint4(0, 0, 0, 0);
+      if (e < W_E && !(a.dbg & 4))
+        x = *reinterpret_cast<const uint4*>(
+            wsplit + (((int64_t)k * a.cout + col_base + j) * nchunk + cc) * (T * 64) + p * 16);
+      rw[v] = x;
+    }
+  };
+  auto commit = [&](int buf) {
+    char* Ab = ldsb + buf * BUF;
+    char* Wb = Ab + T * A_PLANE;
+#pragma unroll
+    for (int v = 0; v < A_V; ++v) {
+      const int e = tid + v * NTHR;
+      if (e < BM * 8) {
+        float x[4] = {ra[v].x, ra[v].y, ra[v].z, ra[v].w};
+        char* dst = Ab + (e >> 3) * kRowB + (e & 7) * 8;
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+          bf16x4 q;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            q[i] = (__bf16)x[i];
+            x[i] -= (float)q[i];
+          }
+          *reinterpret_cast<bf16x4*>(dst + t * A_PLANE) = q;
+        }
       }
     }
+#pragma unroll
+    for (int v = 0; v < W_V; ++v) {
+      const int e = tid + v * NTHR;
+      if (e < W_E) {
+        const int j = e / (T * 4), p = e % (T * 4);
+        *reinterpret_cast<uint4*>(Wb + (p >> 2) * W_PLANE + j * kRowB + (p & 3) * 16) = rw[v];
+      }
+    }
+  };
+
+  if (nstage > 0) {
+    uint32_t rem = bmask;
+    int k = __builtin_ctz(rem);
+    int cc = 0;
+    load_idx(k);
+    issue(k, cc);
+    commit(0);
+    __syncthreads();
+    const int aoff = (wm * 32 + (lane & 31)) * kRowB + (lane >> 5) * 16;
+    const int woff = ((wn * NT) * 32 + (lane & 31)) * kRowB + (lane >> 5) * 16;
+    for (int s = 0; s < nstage; ++s) {
+      const int kcur = k;
+      int kn = k, ccn = cc + 1;
+      if (ccn == nchunk) {
+        ccn = 0;
+        rem &= rem - 1;
+        kn = rem ? __builtin_ctz(rem) : k;
+      }
+      const bool more = s + 1 < nstage;
+      if (more) {
+        if (kn != k && !(a.dbg & 16)) load_idx(kn);
+        issue(kn, ccn);
+      }
+      if (((wmask >> kcur) & 1u) && !(a.dbg & 1)) {
+        const char* Ab = ldsb + (s & 1) * BUF + aoff;
+        const char* Wb = ldsb + (s & 1) * BUF + T * A_PLANE + woff;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          bf16x8 af[T];
+#pragma unroll
+          for (int t = 0; t < T; ++t) af[t] = *reinterpret_cast<const bf16x8*>(Ab + t * A_PLANE + ks * 32);
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            bf16x8 bf[T];
+#pragma unroll
+            for (int t = 0; t < T; ++t)
+              bf[t] = *reinterpret_cast<const bf16x8*>(Wb + t * W_PLANE + nt * 32 * kRowB + ks * 32);
+            if (T == 3) {
+              acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[T - 1], acc[nt], 0, 0, 0);
+              acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[T - 1], bf[0], acc[nt], 0, 0, 0);
+              acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[1], acc[nt], 0, 0, 0);
+            }
+            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[1], acc[nt], 0, 0, 0);
+            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[0], acc[nt], 0, 0, 0);
+            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[0], acc[nt], 0, 0, 0);
+          }
+        }
+      }
+      if (more && !(a.dbg & 8)) commit((s + 1) & 1);
+      __syncthreads();
+      k = kn;
+      cc = ccn;
+    }
+  } else {
+    __syncthreads();
+  }
+  conv_epilogue<NT>(a, acc, orow_s, tile_base, col_base, wm, wn, lane);
+}
+
+// Reference layout [Cout][k][Cin] f32 -> kernel layouts.
+//   terms == 0: [k][Cout][Cin] f32
+//   terms == 2/3: [k][Cout][Cin/32][terms][32] bf16 (term t = bf16 rounding of the remainder)
+__global__ void pack_weight_kernel(const float* __restrict__ w, int cout, int kvol, int cin, int terms,
+                                   void* __restrict__ out) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t total = (int64_t)cout * kvol * cin;
+  if (e >= total) return;
+  const int c = (int)(e % cin);
+  const int k = (int)((e / cin) % kvol);
+  const int o = (int)(e / ((int64_t)cin * kvol));
+  float x = w[e];
+  if (terms == 0) {
+    static_cast<float*>(out)[((int64_t)k * cout + o) * cin + c] = x;
     return;
   }
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    const int col = col_base + (wn * NT + nt) * 32 + cl;
-    const float sc = a.scale ? a.scale[col] : 1.f;
-    const float sh = a.shift ? a.shift[col] : 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int rl = (r & 3) + 8 * (r >> 2) + 4 * h;
-      const int orow = orow_s[wm * 32 + rl];
-      if (orow >= 0) {
-        float v = acc[nt][r] * sc + sh;
-        if (a.residual) v += a.residual[(int64_t)orow * a.cout + col];
-        if (a.relu) v = fmaxf(v, 0.f);
-        a.out[(int64_t)orow * a.ldo + col] = v;
-      }
-    }
+  __bf16* dst = static_cast<__bf16*>(out) +
+                ((((int64_t)k * cout + o) * (cin / 32) + c / 32) * terms) * 32 + (c & 31);
+  for (int t = 0; t < terms; ++t) {
+    const __bf16 q = (__bf16)x;
+    dst[t * 32] = q;
+    x -= (float)q;
   }
 }
 
@@ -306,6 +537,22 @@ static int launch_igemm(const ConvArgs& a, int nz, hipStream_t stream) {
   return M3D_OK;
 }
 
+template <int WM, int WN, int NT, int T>
+static int launch_split(const ConvArgs& a, int nz, hipStream_t stream) {
+  constexpr int BM = 32 * WM, BN = 32 * NT * WN, NTHR = 64 * WM * WN;
+  const size_t lds = (size_t)2 * T * (BM + BN) * kRowB + BM * sizeof(int);
+  static bool attr_done = false;
+  if (!attr_done) {
+    M3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_split_kernel<WM, WN, NT, T>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_done = true;
+  }
+  dim3 grid((unsigned)(a.npad / BM), (unsigned)(a.cout / BN), (unsigned)nz);
+  hipLaunchKernelGGL((conv_igemm_split_kernel<WM, WN, NT, T>), grid, dim3(NTHR), lds, stream, a);
+  M3D_LAUNCH_CHECK();
+  return M3D_OK;
+}
+
 // Tile configuration: the largest row tile that still yields >= ~2 workgroups per CU.
 struct ConvPlan {
   int wm, wn, nt, nz;
@@ -355,7 +602,7 @@ extern "C" int m3d_conv_fwd_f32(const float* d_in0, int c0, const float* d_in1, 
                                 const int32_t* d_out_row, const uint32_t* d_tile_mask, int64_t n,
                                 int64_t npad, const float* d_scale, const float* d_shift,
                                 const float* d_residual, int relu, float* d_out, int64_t ldo,
-                                void* d_ws, size_t ws_bytes, void* stream_) {
+                                int precision, void* d_ws, size_t ws_bytes, void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   M3D_CHECK_ARG(n >= 0, "m3d_conv_fwd_f32: n < 0");
   if (n == 0) return M3D_OK;
@@ -363,6 +610,7 @@ extern "C" int m3d_conv_fwd_f32(const float* d_in0, int c0, const float* d_in1, 
   M3D_CHECK_ARG(c0 > 0 && c1 >= 0 && cout > 0 && k >= 1 && k <= 27, "m3d_conv_fwd_f32: bad channel/kernel sizes");
   M3D_CHECK_ARG((c1 == 0) == (d_in1 == nullptr), "m3d_conv_fwd_f32: in1/c1 mismatch");
   M3D_CHECK_ARG(ldo >= cout, "m3d_conv_fwd_f32: ldo < cout");
+  M3D_CHECK_ARG(precision >= 0 && precision <= 2, "m3d_conv_fwd_f32: unknown precision %d", precision);
   const bool dense = d_nbr == nullptr;
   if (dense) {
     M3D_CHECK_ARG(k == 1 && d_out_row == nullptr && d_tile_mask == nullptr,
@@ -379,6 +627,10 @@ extern "C" int m3d_conv_fwd_f32(const float* d_in0, int c0, const float* d_in1, 
   a.tile_mask = d_tile_mask; a.scale = d_scale; a.shift = d_shift; a.residual = d_residual;
   a.out = d_out; a.slab = nullptr; a.n = n; a.npad = npad; a.ldo = ldo; a.c0 = c0; a.c1 = c1;
   a.cout = cout; a.kvol = k; a.relu = relu;
+  {
+    const char* e = getenv("M3D_DBG");
+    a.dbg = e ? atoi(e) : 0;
+  }
 
   const bool mfma_ok = (c0 % 32 == 0) && (c1 % 32 == 0) && (cout % 32 == 0);
   if (!mfma_ok) {
@@ -399,8 +651,12 @@ extern "C" int m3d_conv_fwd_f32(const float* d_in0, int c0, const float* d_in1, 
     a.slab = static_cast<float*>(d_ws);
   }
   int rc = M3D_EINVAL;
-#define M3D_CASE(WM_, WN_, NT_)                                   \
-  if (p.wm == WM_ && p.wn == WN_ && p.nt == NT_) rc = launch_igemm<WM_, WN_, NT_>(a, p.nz, stream);
+#define M3D_CASE(WM_, WN_, NT_)                                                       \
+  if (p.wm == WM_ && p.wn == WN_ && p.nt == NT_) {                                    \
+    if (precision == M3D_PREC_F32) rc = launch_igemm<WM_, WN_, NT_>(a, p.nz, stream); \
+    else if (precision == M3D_PREC_BF16X3) rc = launch_split<WM_, WN_, NT_, 2>(a, p.nz, stream); \
+    else rc = launch_split<WM_, WN_, NT_, 3>(a, p.nz, stream);                        \
+  }
   M3D_CASE(4, 1, 1) M3D_CASE(4, 1, 2) M3D_CASE(4, 1, 3) M3D_CASE(4, 1, 4)
   M3D_CASE(2, 2, 1) M3D_CASE(2, 2, 2) M3D_CASE(2, 1, 3) M3D_CASE(2, 1, 1)
   M3D_CASE(1, 4, 1) M3D_CASE(1, 3, 1) M3D_CASE(1, 2, 1) M3D_CASE(1, 1, 1)
@@ -414,5 +670,26 @@ extern "C" int m3d_conv_fwd_f32(const float* d_in0, int c0, const float* d_in1, 
                        p.nz);
     M3D_LAUNCH_CHECK();
   }
+  return M3D_OK;
+}
+
+extern "C" size_t m3d_conv_packed_weight_bytes(int cout, int k, int cin, int precision) {
+  const bool mfma_ok = cin % 32 == 0 && cout % 32 == 0;
+  const size_t elems = (size_t)cout * k * cin;
+  if (precision == M3D_PREC_F32 || !mfma_ok) return elems * sizeof(float);
+  return elems * 2 * (precision == M3D_PREC_BF16X3 ? 2 : 3);
+}
+
+extern "C" int m3d_conv_pack_weight(const float* d_weight_ref, int cout, int k, int cin, int precision,
+                                    void* d_out, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  M3D_CHECK_ARG(d_weight_ref && d_out && cout > 0 && k > 0 && cin > 0, "m3d_conv_pack_weight: bad arguments");
+  M3D_CHECK_ARG(precision >= 0 && precision <= 2, "m3d_conv_pack_weight: unknown precision %d", precision);
+  const bool mfma_ok = cin % 32 == 0 && cout % 32 == 0;
+  const int terms = (precision == M3D_PREC_F32 || !mfma_ok) ? 0 : (precision == M3D_PREC_BF16X3 ? 2 : 3);
+  const int64_t total = (int64_t)cout * k * cin;
+  hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, stream, d_weight_ref,
+                     cout, k, cin, terms, d_out);
+  M3D_LAUNCH_CHECK();
   return M3D_OK;
 }

@@ -47,7 +47,7 @@ class _Conv:
 
     def __init__(self, w, scale, shift):
         self.w, self.scale, self.shift = w, scale, shift
-        self.cout = w.shape[1]
+        self.cout = w.cout
 
 
 class _Level:
@@ -56,12 +56,14 @@ class _Level:
 
 
 class SpUNetEngine:
-    def __init__(self, model_or_state: object, cfg: Dict, condition: str = "ScanNet", device="cuda"):
+    def __init__(self, model_or_state: object, cfg: Dict, condition: str = "ScanNet", device="cuda",
+                 precision: str = "f32"):
         """model_or_state: a PPT module (segmentation_amd.spunet.PPT or the reference's) or its state_dict
         ('backbone.*' + 'embedding_table.weight').  cfg: channels / layers / conditions of the backbone."""
         sd = model_or_state.state_dict() if hasattr(model_or_state, "state_dict") else dict(model_or_state)
         sd = {k: v.detach().to("cpu") for k, v in sd.items()}
         self.cfg = cfg
+        self.precision = precision
         self.device = torch.device(device)
         self.channels, self.layers = tuple(cfg["channels"]), tuple(cfg["layers"])
         self.num_stages = len(self.layers) // 2
@@ -72,7 +74,7 @@ class SpUNetEngine:
         self._sd = bsd
 
         def conv(wname, nname=None, bias=None):
-            w = ops.pack_weight(bsd[wname]).to(self.device)
+            w = ops.pack_weight(bsd[wname], precision, self.device)
             if nname is not None:
                 a, c = _fold_norm(bsd, nname, ci, ctx)
             else:
@@ -107,18 +109,18 @@ class SpUNetEngine:
         if d != self.final.cout:
             raise ValueError(f"text dim {d} does not match the backbone output {self.final.cout}")
         cpad = 32 if c <= 32 else 64 if c <= 64 else 96 if c <= 96 else (c + 127) // 128 * 128
-        w = torch.zeros((1, cpad, d), dtype=torch.float32, device=self.device)
-        w[0, :c] = emb
-        self.text = _Conv(w.contiguous(), None, None)
+        w = torch.zeros((cpad, 1, d), dtype=torch.float32, device=self.device)
+        w[:c, 0] = emb
+        self.text = _Conv(ops.pack_weight(w, self.precision), None, None)
         self.n_classes = c
         # folded head: logits = x96 . (E Wf)^T + E bf   (no nonlinearity between `final` and the head)
         wf = self._sd["final.weight"].reshape(self.final.cout, -1).double().to(self.device)
-        wfold = torch.zeros((1, cpad, wf.shape[1]), dtype=torch.float32, device=self.device)
-        wfold[0, :c] = (emb.double() @ wf).float()
+        wfold = torch.zeros((cpad, 1, wf.shape[1]), dtype=torch.float32, device=self.device)
+        wfold[:c, 0] = (emb.double() @ wf).float()
         bfold = torch.zeros((cpad,), dtype=torch.float32, device=self.device)
         if "final.bias" in self._sd:
             bfold[:c] = (emb.double() @ self._sd["final.bias"].double().to(self.device)).float()
-        self.text_folded = _Conv(wfold.contiguous(), None, bfold.contiguous())
+        self.text_folded = _Conv(ops.pack_weight(wfold, self.precision), None, bfold.contiguous())
 
     # ------------------------------------------------------------------ kernel maps
     def build_levels(self, voxel_coords, spatial_shape, batch_size=1):

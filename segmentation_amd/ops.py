@@ -185,27 +185,51 @@ def build_schedule(pair, n, indices=None, mode=0, spatial_shape=None, batch_size
 
 
 # ----------------------------------------------------------------------------- convolution
-def pack_weight(weight):
-    """Reference layout [Cout, k0, k1, k2, Cin] -> kernel layout [K, Cout, Cin] (contiguous)."""
-    cout, cin = weight.shape[0], weight.shape[-1]
-    return weight.detach().reshape(cout, -1, cin).permute(1, 0, 2).contiguous().float()
+PRECISION = {"f32": 0, "bf16x3": 1, "bf16x6": 2}
 
 
-def conv_fwd(in0, weight_packed, sched: Optional[Schedule], n_out, in1=None, scale=None, shift=None,
+@dataclass
+class PackedWeight:
+    """A convolution weight in the kernel's layout for one precision (see m3d_conv_pack_weight)."""
+    data: torch.Tensor  # opaque bytes on the device
+    k: int
+    cout: int
+    cin: int
+    precision: str
+
+
+def pack_weight(weight, precision="f32", device=None):
+    """Reference layout [Cout, k0, k1, k2, Cin] (or [Cout, K, Cin]) f32 -> PackedWeight on `device`."""
+    lib = _lib.load()
+    w = weight.detach().float()
+    cout, cin = w.shape[0], w.shape[-1]
+    w = w.reshape(cout, -1, cin).contiguous()
+    k = w.shape[1]
+    if device is not None:
+        w = w.to(device)
+    _need_cuda(w)
+    prec = PRECISION[precision]
+    nbytes = lib.m3d_conv_packed_weight_bytes(cout, k, cin, prec)
+    out = torch.empty((nbytes,), dtype=torch.uint8, device=w.device)
+    rc = lib.m3d_conv_pack_weight(_ptr(w), cout, k, cin, prec, _ptr(out), _stream())
+    _lib.check(rc, "m3d_conv_pack_weight")
+    return PackedWeight(out, k, cout, cin, precision)
+
+
+def conv_fwd(in0, weight_packed: PackedWeight, sched: Optional[Schedule], n_out, in1=None, scale=None, shift=None,
              residual=None, relu=False, out=None, flop_cout=None):
     """out[row] = act(scale * sum_k W[k] . cat(in0, in1)[nbr[k][t]] + shift + residual[row]).
 
     sched=None is the dense 1x1 case (Custom1x1Subm3d, structure.py:336-347)."""
     lib = _lib.load()
-    _need_cuda(in0, weight_packed)
-    k, cout, cin = weight_packed.shape
+    _need_cuda(in0, weight_packed.data)
+    k, cout, cin = weight_packed.k, weight_packed.cout, weight_packed.cin
     c0 = in0.shape[1]
     c1 = 0 if in1 is None else in1.shape[1]
     if c0 + c1 != cin:
         raise ValueError(f"input channels {c0}+{c1} do not match the weight's {cin}")
     assert in0.is_contiguous() and in0.dtype == torch.float32
     assert in1 is None or (in1.is_contiguous() and in1.dtype == torch.float32)
-    assert weight_packed.is_contiguous() and weight_packed.dtype == torch.float32
     dev = in0.device
     if out is None:
         out = torch.empty((n_out, cout), dtype=torch.float32, device=dev)
@@ -242,10 +266,10 @@ def conv_fwd(in0, weight_packed, sched: Optional[Schedule], n_out, in1=None, sca
         mfma = c0 % 32 == 0 and c1 % 32 == 0 and cout % 32 == 0
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
-    rc = lib.m3d_conv_fwd_f32(_ptr(in0), c0, _ptr(in1), c1, _ptr(weight_packed), k, cout, _ptr(nbr),
+    rc = lib.m3d_conv_fwd_f32(_ptr(in0), c0, _ptr(in1), c1, _ptr(weight_packed.data), k, cout, _ptr(nbr),
                               _ptr(orow), _ptr(mask), n_out, npad, _ptr(scale), _ptr(shift),
-                              _ptr(residual), int(bool(relu)), _ptr(out), ldo, _ptr(ws), ws.numel(),
-                              _stream())
+                              _ptr(residual), int(bool(relu)), _ptr(out), ldo,
+                              PRECISION[weight_packed.precision], _ptr(ws), ws.numel(), _stream())
     _lib.check(rc, "m3d_conv_fwd_f32")
     if prof is not None:
         ev1.record()

@@ -21,6 +21,22 @@ import torch.nn as nn
 from . import ops
 
 
+# How the sparse-convolution modules form their f32 products: "f32" (exact, v_mfma_f32_32x32x2_f32),
+# "bf16x6" (3-term bf16 split, f32-level accuracy) or "bf16x3" (2-term split, ~1e-5 relative).
+_PRECISION = "f32"
+
+
+def set_precision(precision: str):
+    global _PRECISION
+    if precision not in ops.PRECISION:
+        raise ValueError(f"unknown precision {precision!r}; choose from {sorted(ops.PRECISION)}")
+    _PRECISION = precision
+
+
+def get_precision() -> str:
+    return _PRECISION
+
+
 class ConvAlgo(enum.Enum):
     Native = 0
     MaskImplicitGemm = 1
@@ -181,9 +197,9 @@ class SparseConvolution(SparseModule):
 
     # -- weights in the kernel's layout, re-packed only when the parameter changes
     def packed_weight(self):
-        key = (self.weight.data_ptr(), self.weight._version, self.weight.device)
+        key = (self.weight.data_ptr(), self.weight._version, self.weight.device, _PRECISION)
         if self._packed_key != key:
-            self._packed = ops.pack_weight(self.weight)
+            self._packed = ops.pack_weight(self.weight, _PRECISION)
             self._packed_key = key
         return self._packed
 

@@ -31,10 +31,11 @@ def case():
     return dict(cfg=cfg, P=P, b=b, sp=sp, ref=ref, inter=inter, emb=emb)
 
 
-def test_engine_matches_oracle(device, case):
+@pytest.mark.parametrize("prec", ["f32", "bf16x6", "bf16x3"])
+def test_engine_matches_oracle(device, case, prec):
     cfg, P, b = case["cfg"], case["P"], case["b"]
     sd = {("backbone." + k if not k.startswith("embedding_table") else k): v for k, v in P.items()}
-    eng = SpUNetEngine(sd, cfg, "Matterport3D", device)
+    eng = SpUNetEngine(sd, cfg, "Matterport3D", device, precision=prec)
     eng.set_text_embeddings(case["emb"])
     coord, feat = torch.from_numpy(b["coord"]).to(device), torch.from_numpy(b["feat"]).to(device)
     keep = {}

@@ -1,0 +1,96 @@
+"""Host-side logic that needs no GPU: norm folding, synthetic scenes, the spconv/torch_scatter aliases,
+module construction and state-dict naming."""
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import spunet as ospunet
+from segmentation_amd import compat, scenes, sparse, spunet
+from segmentation_amd.engine import _fold_norm
+
+
+def test_fold_norm_matches_oracle_pdnorm():
+    cfg = dict(ospunet.SPUNET34C, layers=(1,) * 8)
+    P = ospunet.make_spunet_params(cfg, seed=3, trained_like=True)
+    ctx = P["embedding_table.weight"][2:3]
+    x = torch.randn(64, 96, generator=torch.Generator().manual_seed(0))
+    ref = ospunet.pdnorm(P, "dec.0.block0.bn2", x, 2, ctx)
+    a, b = _fold_norm(P, "dec.0.block0.bn2", 2, ctx)
+    torch.testing.assert_close(x * a + b, ref, rtol=1e-5, atol=1e-6)
+
+
+def test_scene_generator_is_seeded_and_centred():
+    a = scenes.make_scene(seed=3, target_voxels=2000)
+    b = scenes.make_scene(seed=3, target_voxels=2000)
+    assert np.array_equal(a["coord"], b["coord"]) and np.array_equal(a["color"], b["color"])
+    c = a["coord"]
+    assert c.dtype == np.float32 and a["feat"].dtype == np.float32 and a["color"].dtype == np.uint8
+    assert abs(c[:, 0].min() + c[:, 0].max()) < 1e-4 and abs(c[:, 2].min()) < 1e-6  # CenterShift(apply_z)
+    assert a["feat"].min() >= -1.0 and a["feat"].max() <= 1.0
+    e = scenes.text_embeddings(20, 768)
+    np.testing.assert_allclose(np.linalg.norm(e, axis=1), 1.0, rtol=1e-5)
+
+
+def test_compat_aliases_resolve():
+    mods = compat.build_modules()
+    spp = mods["spconv.pytorch"]
+    for name in ("SparseConvTensor", "SubMConv3d", "SparseConv3d", "SparseInverseConv3d", "SparseSequential",
+                 "SparseModule", "ConvAlgo"):
+        assert hasattr(spp, name)
+    assert spp.ConvAlgo.Native is sparse.ConvAlgo.Native
+    assert spp.modules.is_spconv_module(sparse.SubMConv3d(4, 4, 3))
+    assert not spp.modules.is_spconv_module(torch.nn.ReLU())
+    assert hasattr(spp.core, "ImplicitGemmIndiceData")
+    with pytest.raises(NotImplementedError):
+        spp.ops.indice_avgpool_implicit_gemm()
+    # the reference's isinstance-based init must not treat the other conv classes as SubMConv3d
+    assert not isinstance(sparse.SparseConv3d(4, 4, 2, 2), sparse.SubMConv3d)
+    assert not isinstance(sparse.SparseInverseConv3d(4, 4, 2, "k"), sparse.SubMConv3d)
+
+
+def test_scatter_and_segment_csr():
+    src = torch.tensor([[1.0, 2.0], [3.0, 4.0], [5.0, 6.0], [7.0, 8.0]])
+    idx = torch.tensor([1, 0, 1, 1])
+    out = sparse.scatter(src, idx, dim=0, reduce="mean")
+    torch.testing.assert_close(out, torch.tensor([[3.0, 4.0], [13.0 / 3, 16.0 / 3]]))
+    out = sparse.scatter(src, idx, dim=0, reduce="sum")
+    torch.testing.assert_close(out, torch.tensor([[3.0, 4.0], [13.0, 16.0]]))
+    seg = sparse.segment_csr(src, torch.tensor([0, 1, 4]), reduce="mean")
+    torch.testing.assert_close(seg, torch.tensor([[1.0, 2.0], [5.0, 6.0]]))
+
+
+def test_sparse_sequential_passes_lists_to_sparse_modules():
+    class Tag(sparse.SparseModule):
+        def forward(self, x):
+            t, cond, ctx = x
+            return t.replace_feature(t.features + 1), cond, ctx
+
+    seq = sparse.SparseSequential(Tag(), Tag())
+    t = sparse.SparseConvTensor(torch.zeros(3, 2), torch.zeros(3, 4, dtype=torch.int32), [4, 4, 4], 1)
+    out, cond, ctx = seq([t, "ScanNet", None])
+    assert cond == "ScanNet" and torch.equal(out.features, torch.full((3, 2), 2.0))
+    assert out.indice_dict is t.indice_dict  # replace_feature shares the kernel-map cache
+    seq2 = sparse.SparseSequential(torch.nn.ReLU())
+    assert torch.equal(seq2(t.replace_feature(torch.tensor([[-1.0, 2.0]] * 3))).features[0], torch.tensor([0.0, 2.0]))
+
+
+def test_model_state_dict_matches_oracle_parameter_names():
+    cfg = ospunet.SPUNET34C
+    P = ospunet.make_spunet_params(cfg, seed=0)
+    model = spunet.PPT(spunet.SpUNet(), cfg["conditions"], 256)
+    sd = model.state_dict()
+    want = {("backbone." + k if not k.startswith("embedding_table") else k) for k in P}
+    have = {k for k in sd if not k.endswith("num_batches_tracked")}
+    assert want == have
+    for k, v in P.items():
+        name = "backbone." + k if not k.startswith("embedding_table") else k
+        assert tuple(sd[name].shape) == tuple(v.shape), name
+    spunet.load_oracle_params(model, P)
+    # reference init rules (v1m3:362-378): SubM convs trunc_normal(0.02), modulation zero-initialised
+    m2 = spunet.SpUNet()
+    assert abs(float(m2.enc[0].block0.conv1.weight.std()) - 0.02) < 2e-3
+    assert float(m2.enc[0].block0.bn1.modulation[1].weight.abs().max()) == 0.0
+    n_params = sum(p.numel() for p in m2.parameters())
+    assert 35e6 < n_params < 60e6

@@ -1,0 +1,62 @@
+"""World-size-2 rehearsal of the scene-sharded path on the CPU (gloo): assignment covers every scene exactly
+once, the job-level reduction takes the max time and the total units, and no collective is needed in between."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from segmentation_amd import sharding
+
+
+def test_lpt_assignment_is_a_partition_and_balanced():
+    sizes = [250_000, 150_000, 240_000, 160_000, 200_000, 199_000, 151_000]
+    for world in (1, 2, 4, 8):
+        parts = sharding.assign_scenes(sizes, world)
+        flat = sorted(i for p in parts for i in p)
+        assert flat == list(range(len(sizes)))
+        loads = [sum(sizes[i] for i in p) for p in parts]
+        if world <= 4:
+            assert max(loads) - min(loads) <= max(sizes)
+    assert sharding.round_robin(10, 4, 1) == [1, 5, 9]
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sizes = [100 + 10 * i for i in range(7)]
+        mine = sharding.assign_scenes(sizes, world)[rank]
+        # stand-in for the per-scene GPU work: units = sum of the scene sizes this rank owns
+        units = float(sum(sizes[i] for i in mine))
+        elapsed = 1.0 + 0.5 * rank
+        dist.barrier()
+        t, u = sharding.reduce_job(elapsed, units, dist)
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine)
+        out[rank] = (t, u, gathered)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_gloo():
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    sizes = [100 + 10 * i for i in range(7)]
+    for rank in range(world):
+        t, u, gathered = out[rank]
+        assert t == 1.5                       # max over ranks
+        assert u == float(sum(sizes))         # total units over ranks
+        assert sorted(i for p in gathered for i in p) == list(range(7))

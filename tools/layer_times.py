@@ -6,7 +6,7 @@ import bench
 from segmentation_amd import ops, scenes
 
 dev = torch.device("cuda:0")
-eng, model, cfg = bench.build_engine(dev)
+eng, model, cfg = bench.build_engine(dev, sys.argv[2] if len(sys.argv) > 2 else "f32")
 tv = int(sys.argv[1]) if len(sys.argv) > 1 else bench.TARGET_VOXELS
 sc = scenes.make_scene(seed=0, target_voxels=tv)
 n = sc["coord"].shape[0]
