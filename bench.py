@@ -140,8 +140,13 @@ def main():
         secs = sum(t for _, t in ig)
         nl = max(len(ig), 1)
         achieved = flops / secs / 1e12 if secs > 0 else 0.0
+        # HBM bytes per launch of the same kernels from the committed rocprofv3 --pmc passes (separate runs)
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", f"r01_{args.precision}_conv_pmc.json")
+        if os.path.exists(pmc):
+            traffic = json.load(open(pmc))["all_conv_igemm"]["traffic_bytes_per_launch"]
         roofline = dict(bound="mfma", achieved=achieved, peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
-                        frac=achieved / PEAK_F32_MFMA_TFLOPS, traffic=None,
+                        frac=achieved / PEAK_F32_MFMA_TFLOPS, traffic=traffic,
                         kernel="m3d::conv_igemm_f32_kernel<*> (all tile shapes)", launches_per_step=nl // min(args.steps, 5),
                         flop_per_launch=flops / nl, avg_launch_us=secs / nl * 1e6,
                         conv_share_of_step=secs / min(args.steps, 5) / (elapsed / args.steps))
