@@ -142,8 +142,26 @@ int m3d_conv_fwd_f32(const float* d_in0, int c0, const float* d_in1, int c1,
                      const float* d_weight, int k, int cout, const int32_t* d_nbr,
                      const int32_t* d_out_row, const uint32_t* d_tile_mask, int64_t n,
                      int64_t npad, const float* d_scale, const float* d_shift,
-                     const float* d_residual, int relu, float* d_out, int64_t ldo, int precision,
-                     void* d_ws, size_t ws_bytes, void* stream);
+                     const float* d_residual, int relu, float* d_out, int64_t ldo,
+                     void* d_out_split, int out_terms, int precision, void* d_ws, size_t ws_bytes,
+                     void* stream);
+
+/* Same convolution with the activations in the engine-internal split format "sf32":
+ *   [rows + 1][C/32][terms][32] bf16, term t = bf16 rounding of what terms < t left over, row `rows`
+ *   all zero (missing neighbours gather it).  Inputs are moved to LDS by per-lane-addressed LDS-DMA
+ *   (global_load_lds_dwordx4); products as in M3D_PREC_BF16X3 (terms = 2) / M3D_PREC_BF16X6 (terms = 3).
+ *   d_weight: m3d_conv_pack_weight output for that precision.  Outputs: d_out (f32, may be NULL) and/or
+ *   d_out_split (sf32 with cout/32 groups, may be NULL); m3d_conv_fwd_f32 can write d_out_split too
+ *   (out_terms = 0: none); the kernel that writes d_out_split also clears its all-zero row.
+ *   No counterpart in the reference: a storage format of this engine. */
+int m3d_conv_fwd_sf32(const void* d_in0, int c0, int64_t rows0, const void* d_in1, int c1,
+                      int64_t rows1, const void* d_weight, int k, int cout, const int32_t* d_nbr,
+                      const int32_t* d_out_row, const uint32_t* d_tile_mask, int64_t n, int64_t npad,
+                      const float* d_scale, const float* d_shift, const float* d_residual, int relu,
+                      float* d_out, int64_t ldo, void* d_out_split, int terms, void* d_ws,
+                      size_t ws_bytes, void* stream);
+size_t m3d_sf32_bytes(int64_t n, int c, int terms);
+int m3d_split_f32(const float* d_in, int64_t n, int c, int terms, void* d_out, void* stream);
 
 /* Weight conversion for m3d_conv_fwd_f32: d_weight_ref is the reference layout [cout, k, cin] f32
  * (spconv's [Cout, k0, k1, k2, Cin] flattened; structure.py:338 relies on it for k = 1). */

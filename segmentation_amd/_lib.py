@@ -31,7 +31,11 @@ SIGNATURES = {
                                   _vp, _vp, _vp, _vp, _sz, _vp]),
     "m3d_conv_workspace_bytes": (_sz, [_i64, _int, _int]),
     "m3d_conv_fwd_f32": (_int, [_vp, _int, _vp, _int, _vp, _int, _int, _vp, _vp, _vp, _i64, _i64,
-                                _vp, _vp, _vp, _int, _vp, _i64, _int, _vp, _sz, _vp]),
+                                _vp, _vp, _vp, _int, _vp, _i64, _vp, _int, _int, _vp, _sz, _vp]),
+    "m3d_conv_fwd_sf32": (_int, [_vp, _int, _i64, _vp, _int, _i64, _vp, _int, _int, _vp, _vp, _vp, _i64, _i64,
+                                 _vp, _vp, _vp, _int, _vp, _i64, _vp, _int, _vp, _sz, _vp]),
+    "m3d_sf32_bytes": (_sz, [_i64, _int, _int]),
+    "m3d_split_f32": (_int, [_vp, _i64, _int, _int, _vp, _vp]),
     "m3d_conv_packed_weight_bytes": (_sz, [_int, _int, _int, _int]),
     "m3d_conv_pack_weight": (_int, [_vp, _int, _int, _int, _int, _vp, _vp]),
     "m3d_argmax_rows": (_int, [_vp, _i64, _int, _i64, _vp, _vp]),

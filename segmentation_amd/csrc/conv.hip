@@ -41,10 +41,34 @@ struct ConvArgs {
   int64_t n, npad, ldo;
   int c0, c1, cout, kvol, relu;
   int dbg;  // timing-only ablation bits (M3D_DBG); 0 in normal operation
+  // split-format ("sf32") operands of the LDS-DMA kernel: [rows + 1][C/32][T][32] bf16, last row zero
+  const char* s0;
+  const char* s1;
+  int64_t zero0, zero1;  // index of the all-zero row of s0 / s1
+  char* out_split;       // optional sf32 copy of the output (cout/32 groups per row)
+  int terms;             // T of out_split
 };
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+// One element of an sf32 tensor: term t = bf16 rounding of what the earlier terms left over.
+__device__ inline void store_split(char* base, int64_t row, int col, int c, int terms, float v) {
+  __bf16* p = reinterpret_cast<__bf16*>(base + ((row * (c >> 5) + (col >> 5)) * terms) * 64) + (col & 31);
+  for (int t = 0; t < terms; ++t) {
+    const __bf16 q = (__bf16)v;
+    p[t * 32] = q;
+    v -= (float)q;
+  }
+}
+
+// The all-zero row (index n) of an sf32 output; called by one workgroup of the kernel that writes the output.
+__device__ inline void clear_zero_row(const ConvArgs& a) {
+  if (a.out_split == nullptr) return;
+  const int words = a.cout * a.terms / 2;  // 4-byte words in one row
+  uint32_t* p = reinterpret_cast<uint32_t*>(a.out_split + (int64_t)a.n * a.cout * a.terms * 2);
+  for (int i = threadIdx.x; i < words; i += blockDim.x) p[i] = 0u;
+}
 
 // Accumulator register r of a 32x32 tile is row (r&3) + 8*(r>>2) + 4*(lane>>5), column lane&31.
 template <int NT>
@@ -64,6 +88,7 @@ __device__ inline void conv_epilogue(const ConvArgs& a, const floatx16 (&acc)[NT
     }
     return;
   }
+  if (blockIdx.x == 0 && blockIdx.y == 0) clear_zero_row(a);
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     const int col = col_base + (wn * NT + nt) * 32 + cl;
@@ -77,7 +102,8 @@ __device__ inline void conv_epilogue(const ConvArgs& a, const floatx16 (&acc)[NT
         float v = acc[nt][r] * sc + sh;
         if (a.residual) v += a.residual[(int64_t)orow * a.cout + col];
         if (a.relu) v = fmaxf(v, 0.f);
-        a.out[(int64_t)orow * a.ldo + col] = v;
+        if (a.out) a.out[(int64_t)orow * a.ldo + col] = v;
+        if (a.out_split) store_split(a.out_split, orow, col, a.cout, a.terms, v);
       }
     }
   }
@@ -443,6 +469,182 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_split_kernel(ConvArgs
   conv_epilogue<NT>(a, acc, orow_s, tile_base, col_base, wm, wn, lane);
 }
 
+// ------------------------------------------------------------------------------------------
+// LDS-DMA variant of the split-bf16 kernel.  Activations arrive already split ("sf32":
+// [rows + 1][C/32][T][32] bf16, the extra row all zero), so a stage is a pure byte move: every lane
+// issues global_load_lds_dwordx4 with its own source address (row gather) and the hardware writes the
+// 64 lanes' 16-B pieces to consecutive LDS slots -- no staging registers, no VALU, no ds_write.
+// LDS image: one row per gathered row, SLOTS 16-B slots (8 for T = 2, 16 for T = 3, 12 used); slot
+// p' of row r holds piece p' ^ swz(r), so the fragment reads (16 lanes, distinct rows, same piece)
+// hit distinct banks although the image is lane-linear.  Missing neighbours read the zero row.
+// Pipeline: two LDS buffers; the DMA of stage s+2 is issued right after stage s has been consumed and
+// lands during stage s+1 (counted s_waitcnt vmcnt, raw s_barrier); the kernel map of the tile is
+// staged in LDS once so that no ordinary global load sits between DMAs.
+template <int T>
+struct DmaGeom {
+  static constexpr int SLOTS = T == 2 ? 8 : 16;
+  static constexpr int PIECES = 4 * T;
+  static constexpr int ROWB = SLOTS * 16;
+  __device__ static inline int swz(int r) { return T == 2 ? ((r >> 1) & 7) : (r & 15); }
+};
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+template <int WM, int WN, int NT, int T>
+__global__ __launch_bounds__(64 * WM * WN) void conv_igemm_dma_kernel(ConvArgs a) {
+  using G = DmaGeom<T>;
+  constexpr int BM = 32 * WM, BN = 32 * NT * WN, NTHR = 64 * WM * WN;
+  constexpr int A_BYTES = BM * G::ROWB, W_BYTES = BN * G::ROWB, BUF = A_BYTES + W_BYTES;
+  constexpr int A_V = BM * G::SLOTS / NTHR, W_V = BN * G::SLOTS / NTHR;
+  static_assert(BM * G::SLOTS % NTHR == 0 && BN * G::SLOTS % NTHR == 0, "every wave must issue the same DMA count");
+  extern __shared__ __align__(16) char ldsb[];
+  int* idx_s = reinterpret_cast<int*>(ldsb + 2 * BUF);  // [kvol][BM]
+  int* orow_s = idx_s + a.kvol * BM;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int64_t tile_base = xcd_tile(blockIdx.x, gridDim.x) * BM;
+  const int col_base = blockIdx.y * BN;
+  const int cin = a.c0 + a.c1;
+  const int nchunk = cin / kBK;
+  const int g0 = a.c0 / kBK;
+  const char* wsplit = reinterpret_cast<const char*>(a.weight);
+  const int64_t rowb0 = (int64_t)g0 * (G::PIECES * 16), rowb1 = (int64_t)(a.c1 / kBK) * (G::PIECES * 16);
+
+  uint32_t bmask, wmask;
+  conv_masks<WM>(a, tile_base, wm, bmask, wmask);
+
+  for (int r = tid; r < BM; r += NTHR) {
+    const int64_t t = tile_base + r;
+    orow_s[r] = a.out_row ? a.out_row[t] : (t < a.n ? (int)t : -1);
+  }
+  for (int e = tid; e < a.kvol * BM; e += NTHR) {
+    const int k = e / BM, r = e % BM;
+    const int64_t t = tile_base + r;
+    idx_s[e] = a.nbr ? a.nbr[(int64_t)k * a.npad + t] : (t < a.n ? (int)t : -1);
+  }
+  __syncthreads();
+
+  floatx16 acc[NT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
+
+  const int nstage = __popc(bmask) * nchunk;
+
+  // this thread's slots: e = v * NTHR + tid -> (row, physical slot p'), logical piece p = p' ^ swz(row)
+  auto issue = [&](int k, int cc, int buf) {
+    const char* src;
+    int64_t rowb, zero;
+    int grp;
+    if (cc < g0) { src = a.s0; rowb = rowb0; zero = a.zero0; grp = cc; }
+    else { src = a.s1; rowb = rowb1; zero = a.zero1; grp = cc - g0; }
+    char* Ab = ldsb + buf * BUF;
+#pragma unroll
+    for (int v = 0; v < A_V; ++v) {
+      const int e = v * NTHR + tid;
+      const int r = e / G::SLOTS, p = (e % G::SLOTS) ^ G::swz(r);
+      int id = idx_s[k * BM + r];
+      const int64_t row = id < 0 ? zero : (int64_t)id;
+      const char* g = src + row * rowb + grp * (G::PIECES * 16) + p * 16;
+      if (T == 2 || p < G::PIECES)
+        __builtin_amdgcn_global_load_lds(g, (lds_ptr_t)(Ab + (v * NTHR + wave * 64) * 16), 16, 0, 0);
+    }
+    char* Wb = Ab + A_BYTES;
+#pragma unroll
+    for (int v = 0; v < W_V; ++v) {
+      const int e = v * NTHR + tid;
+      const int j = e / G::SLOTS, p = (e % G::SLOTS) ^ G::swz(j);
+      const char* g = wsplit + (((int64_t)k * a.cout + col_base + j) * nchunk + cc) * (G::PIECES * 16) + p * 16;
+      if (T == 2 || p < G::PIECES)
+        __builtin_amdgcn_global_load_lds(g, (lds_ptr_t)(Wb + (v * NTHR + wave * 64) * 16), 16, 0, 0);
+    }
+  };
+
+  if (nstage > 0) {
+    // stage iterator (k, cc) for issue, advanced one stage at a time
+    uint32_t rem = bmask;
+    int ik = __builtin_ctz(rem), icc = 0;
+    auto advance = [&]() {
+      if (++icc == nchunk) {
+        icc = 0;
+        rem &= rem - 1;
+        ik = rem ? __builtin_ctz(rem) : ik;
+      }
+    };
+    issue(ik, icc, 0);
+    advance();
+    if (nstage > 1) {
+      issue(ik, icc, 1);
+      advance();
+    }
+    uint32_t crem = bmask;
+    int ck = __builtin_ctz(crem), ccc = 0;
+    const int r32 = lane & 31, h = lane >> 5;
+    const int arow = wm * 32 + r32;
+    for (int s = 0; s < nstage; ++s) {
+      if (s + 1 < nstage) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_V + W_V) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if ((wmask >> ck) & 1u) {
+        const char* Ab = ldsb + (s & 1) * BUF + arow * G::ROWB;
+        const char* Wb = ldsb + (s & 1) * BUF + A_BYTES;
+        const int asw = G::swz(arow);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          bf16x8 af[T];
+#pragma unroll
+          for (int t = 0; t < T; ++t)
+            af[t] = *reinterpret_cast<const bf16x8*>(Ab + (((t * 4 + ks * 2 + h) ^ asw) * 16));
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            const int j = (wn * NT + nt) * 32 + r32;
+            const int jsw = G::swz(j);
+            bf16x8 bf[T];
+#pragma unroll
+            for (int t = 0; t < T; ++t)
+              bf[t] = *reinterpret_cast<const bf16x8*>(Wb + j * G::ROWB + (((t * 4 + ks * 2 + h) ^ jsw) * 16));
+            if (T == 3) {
+              acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[T - 1], acc[nt], 0, 0, 0);
+              acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[T - 1], bf[0], acc[nt], 0, 0, 0);
+              acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[1], acc[nt], 0, 0, 0);
+            }
+            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[1], acc[nt], 0, 0, 0);
+            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[0], acc[nt], 0, 0, 0);
+            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[0], acc[nt], 0, 0, 0);
+          }
+        }
+      }
+      if (++ccc == nchunk) {
+        ccc = 0;
+        crem &= crem - 1;
+        ck = crem ? __builtin_ctz(crem) : ck;
+      }
+      // every wave has consumed buffer (s & 1): refill it with stage s + 2
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (s + 2 < nstage) {
+        issue(ik, icc, s & 1);
+        advance();
+      }
+    }
+  }
+  conv_epilogue<NT>(a, acc, orow_s, tile_base, col_base, wm, wn, lane);
+}
+
+// f32 [n][c] -> sf32 [n + 1][c/32][terms][32] bf16 (row n zero).  One thread per element.
+__global__ void split_f32_kernel(const float* __restrict__ in, int64_t n, int c, int terms, char* __restrict__ out) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (n + 1) * c) return;
+  const int64_t row = e / c;
+  const int col = (int)(e % c);
+  store_split(out, row, col, c, terms, row < n ? in[e] : 0.f);
+}
+
 // Reference layout [Cout][k][Cin] f32 -> kernel layouts.
 //   terms == 0: [k][Cout][Cin] f32
 //   terms == 2/3: [k][Cout][Cin/32][terms][32] bf16 (term t = bf16 rounding of the remainder)
@@ -470,6 +672,7 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, int cout, int kv
 
 // Fixed-order reduction of the split-K slabs + epilogue.
 __global__ __launch_bounds__(256) void conv_reduce_kernel(ConvArgs a, int nz) {
+  if (blockIdx.x == 0) clear_zero_row(a);
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t total = a.npad * a.cout;
   if (e >= total) return;
@@ -482,7 +685,8 @@ __global__ __launch_bounds__(256) void conv_reduce_kernel(ConvArgs a, int nz) {
   v = v * (a.scale ? a.scale[col] : 1.f) + (a.shift ? a.shift[col] : 0.f);
   if (a.residual) v += a.residual[(int64_t)orow * a.cout + col];
   if (a.relu) v = fmaxf(v, 0.f);
-  a.out[(int64_t)orow * a.ldo + col] = v;
+  if (a.out) a.out[(int64_t)orow * a.ldo + col] = v;
+  if (a.out_split) store_split(a.out_split, orow, col, a.cout, a.terms, v);
 }
 
 // Any channel counts (used for the 3-channel stem and for shapes that are not multiples of 32):
@@ -497,6 +701,7 @@ __global__ __launch_bounds__(256) void conv_direct_f32_kernel(ConvArgs a) {
     __syncthreads();
   }
   const float* w = w_in_lds ? wsm : a.weight;
+  if (blockIdx.x == 0) clear_zero_row(a);
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= a.npad * a.cout) return;
   const int64_t t = e / a.cout;
@@ -518,7 +723,8 @@ __global__ __launch_bounds__(256) void conv_direct_f32_kernel(ConvArgs a) {
   float v = acc * (a.scale ? a.scale[col] : 1.f) + (a.shift ? a.shift[col] : 0.f);
   if (a.residual) v += a.residual[(int64_t)orow * a.cout + col];
   if (a.relu) v = fmaxf(v, 0.f);
-  a.out[(int64_t)orow * a.ldo + col] = v;
+  if (a.out) a.out[(int64_t)orow * a.ldo + col] = v;
+  if (a.out_split) store_split(a.out_split, orow, col, a.cout, a.terms, v);
 }
 
 template <int WM, int WN, int NT>
@@ -549,6 +755,22 @@ static int launch_split(const ConvArgs& a, int nz, hipStream_t stream) {
   }
   dim3 grid((unsigned)(a.npad / BM), (unsigned)(a.cout / BN), (unsigned)nz);
   hipLaunchKernelGGL((conv_igemm_split_kernel<WM, WN, NT, T>), grid, dim3(NTHR), lds, stream, a);
+  M3D_LAUNCH_CHECK();
+  return M3D_OK;
+}
+
+template <int WM, int WN, int NT, int T>
+static int launch_dma(const ConvArgs& a, int nz, hipStream_t stream) {
+  constexpr int BM = 32 * WM, BN = 32 * NT * WN, NTHR = 64 * WM * WN;
+  const size_t lds = (size_t)2 * (BM + BN) * DmaGeom<T>::ROWB + (size_t)(a.kvol + 1) * BM * sizeof(int);
+  static size_t attr_lds = 0;
+  if (lds > attr_lds) {
+    M3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_dma_kernel<WM, WN, NT, T>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_lds = lds;
+  }
+  dim3 grid((unsigned)(a.npad / BM), (unsigned)(a.cout / BN), (unsigned)nz);
+  hipLaunchKernelGGL((conv_igemm_dma_kernel<WM, WN, NT, T>), grid, dim3(NTHR), lds, stream, a);
   M3D_LAUNCH_CHECK();
   return M3D_OK;
 }
@@ -597,79 +819,168 @@ extern "C" size_t m3d_conv_workspace_bytes(int64_t n, int cout, int k) {
   return align_up((size_t)p.nz * npad * cout * sizeof(float));
 }
 
-extern "C" int m3d_conv_fwd_f32(const float* d_in0, int c0, const float* d_in1, int c1,
-                                const float* d_weight, int k, int cout, const int32_t* d_nbr,
-                                const int32_t* d_out_row, const uint32_t* d_tile_mask, int64_t n,
-                                int64_t npad, const float* d_scale, const float* d_shift,
-                                const float* d_residual, int relu, float* d_out, int64_t ldo,
-                                int precision, void* d_ws, size_t ws_bytes, void* stream_) {
-  hipStream_t stream = static_cast<hipStream_t>(stream_);
-  M3D_CHECK_ARG(n >= 0, "m3d_conv_fwd_f32: n < 0");
-  if (n == 0) return M3D_OK;
-  M3D_CHECK_ARG(d_in0 && d_weight && d_out, "m3d_conv_fwd_f32: null pointer");
-  M3D_CHECK_ARG(c0 > 0 && c1 >= 0 && cout > 0 && k >= 1 && k <= 27, "m3d_conv_fwd_f32: bad channel/kernel sizes");
-  M3D_CHECK_ARG((c1 == 0) == (d_in1 == nullptr), "m3d_conv_fwd_f32: in1/c1 mismatch");
-  M3D_CHECK_ARG(ldo >= cout, "m3d_conv_fwd_f32: ldo < cout");
-  M3D_CHECK_ARG(precision >= 0 && precision <= 2, "m3d_conv_fwd_f32: unknown precision %d", precision);
-  const bool dense = d_nbr == nullptr;
-  if (dense) {
-    M3D_CHECK_ARG(k == 1 && d_out_row == nullptr && d_tile_mask == nullptr,
-                  "m3d_conv_fwd_f32: dense mode needs k == 1 and no schedule");
-    npad = m3d_schedule_npad(n);
-  } else {
-    M3D_CHECK_ARG(d_out_row && d_tile_mask, "m3d_conv_fwd_f32: schedule pointers missing");
-    M3D_CHECK_ARG(npad >= n && npad % 128 == 0, "m3d_conv_fwd_f32: npad=%lld must be a multiple of 128 >= n",
-                  (long long)npad);
-  }
-  M3D_CHECK_ARG(npad < (int64_t)1 << 31, "m3d_conv_fwd_f32: too many rows");
-  ConvArgs a;
-  a.in0 = d_in0; a.in1 = d_in1; a.weight = d_weight; a.nbr = d_nbr; a.out_row = d_out_row;
-  a.tile_mask = d_tile_mask; a.scale = d_scale; a.shift = d_shift; a.residual = d_residual;
-  a.out = d_out; a.slab = nullptr; a.n = n; a.npad = npad; a.ldo = ldo; a.c0 = c0; a.c1 = c1;
-  a.cout = cout; a.kvol = k; a.relu = relu;
+// mode: 0 exact f32, 1/2 split-bf16 with in-kernel activation split (T = 2/3), 3/4 LDS-DMA on sf32 inputs (T = 2/3)
+static int run_conv(ConvArgs& a, int mode, bool mfma_ok, void* d_ws, size_t ws_bytes, hipStream_t stream,
+                    const char* who) {
   {
     const char* e = getenv("M3D_DBG");
     a.dbg = e ? atoi(e) : 0;
   }
-
-  const bool mfma_ok = (c0 % 32 == 0) && (c1 % 32 == 0) && (cout % 32 == 0);
+  a.slab = nullptr;
   if (!mfma_ok) {
-    const int64_t total = npad * cout;
-    const size_t wbytes = (size_t)k * cout * (c0 + c1) * sizeof(float);
+    if (mode >= 3) {
+      set_error("%s: channel counts must be multiples of 32", who);
+      return M3D_EINVAL;
+    }
+    const int64_t total = a.npad * a.cout;
+    const size_t wbytes = (size_t)a.kvol * a.cout * (a.c0 + a.c1) * sizeof(float);
     const size_t lds = wbytes <= 60 * 1024 ? wbytes : 0;
     hipLaunchKernelGGL(conv_direct_f32_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), lds, stream, a);
     M3D_LAUNCH_CHECK();
     return M3D_OK;
   }
-  const ConvPlan p = plan_conv(npad, cout, k);
+  ConvPlan p = plan_conv(a.npad, a.cout, a.kvol);
+  if (mode >= 3 && p.wm == 1 && p.wn == 3) p = ConvPlan{1, 1, 3, p.nz};  // equal DMA count per wave
   if (p.nz > 1) {
-    const size_t need = (size_t)p.nz * npad * cout * sizeof(float);
+    const size_t need = (size_t)p.nz * a.npad * a.cout * sizeof(float);
     if (d_ws == nullptr || ws_bytes < need) {
-      set_error("m3d_conv_fwd_f32: workspace too small (%zu given, %zu needed)", ws_bytes, need);
+      set_error("%s: workspace too small (%zu given, %zu needed)", who, ws_bytes, need);
       return M3D_ENOSPC;
     }
     a.slab = static_cast<float*>(d_ws);
   }
   int rc = M3D_EINVAL;
-#define M3D_CASE(WM_, WN_, NT_)                                                       \
-  if (p.wm == WM_ && p.wn == WN_ && p.nt == NT_) {                                    \
-    if (precision == M3D_PREC_F32) rc = launch_igemm<WM_, WN_, NT_>(a, p.nz, stream); \
-    else if (precision == M3D_PREC_BF16X3) rc = launch_split<WM_, WN_, NT_, 2>(a, p.nz, stream); \
-    else rc = launch_split<WM_, WN_, NT_, 3>(a, p.nz, stream);                        \
+#define M3D_CASE(WM_, WN_, NT_)                                                     \
+  if (p.wm == WM_ && p.wn == WN_ && p.nt == NT_) {                                  \
+    if (mode == 0) rc = launch_igemm<WM_, WN_, NT_>(a, p.nz, stream);               \
+    else if (mode == 1) rc = launch_split<WM_, WN_, NT_, 2>(a, p.nz, stream);       \
+    else if (mode == 2) rc = launch_split<WM_, WN_, NT_, 3>(a, p.nz, stream);       \
   }
-  M3D_CASE(4, 1, 1) M3D_CASE(4, 1, 2) M3D_CASE(4, 1, 3) M3D_CASE(4, 1, 4)
-  M3D_CASE(2, 2, 1) M3D_CASE(2, 2, 2) M3D_CASE(2, 1, 3) M3D_CASE(2, 1, 1)
-  M3D_CASE(1, 4, 1) M3D_CASE(1, 3, 1) M3D_CASE(1, 2, 1) M3D_CASE(1, 1, 1)
+#define M3D_CASE_DMA(WM_, WN_, NT_)                                                 \
+  if (p.wm == WM_ && p.wn == WN_ && p.nt == NT_) {                                  \
+    if (mode == 3) rc = launch_dma<WM_, WN_, NT_, 2>(a, p.nz, stream);              \
+    else if (mode == 4) rc = launch_dma<WM_, WN_, NT_, 3>(a, p.nz, stream);         \
+  }
+  if (mode < 3) {
+    M3D_CASE(4, 1, 1) M3D_CASE(4, 1, 2) M3D_CASE(4, 1, 3) M3D_CASE(4, 1, 4)
+    M3D_CASE(2, 2, 1) M3D_CASE(2, 2, 2) M3D_CASE(2, 1, 3) M3D_CASE(2, 1, 1)
+    M3D_CASE(1, 4, 1) M3D_CASE(1, 3, 1) M3D_CASE(1, 2, 1) M3D_CASE(1, 1, 1)
+  } else {
+    M3D_CASE_DMA(4, 1, 1) M3D_CASE_DMA(4, 1, 2) M3D_CASE_DMA(4, 1, 3) M3D_CASE_DMA(4, 1, 4)
+    M3D_CASE_DMA(2, 2, 1) M3D_CASE_DMA(2, 2, 2) M3D_CASE_DMA(2, 1, 3) M3D_CASE_DMA(2, 1, 1)
+    M3D_CASE_DMA(1, 4, 1) M3D_CASE_DMA(1, 1, 3) M3D_CASE_DMA(1, 2, 1) M3D_CASE_DMA(1, 1, 1)
+  }
 #undef M3D_CASE
+#undef M3D_CASE_DMA
   if (rc != M3D_OK) {
-    if (rc == M3D_EINVAL) set_error("m3d_conv_fwd_f32: no kernel for plan (%d,%d,%d)", p.wm, p.wn, p.nt);
+    if (rc == M3D_EINVAL) set_error("%s: no kernel for plan (%d,%d,%d)", who, p.wm, p.wn, p.nt);
     return rc;
   }
   if (p.nz > 1) {
-    hipLaunchKernelGGL(conv_reduce_kernel, dim3((unsigned)cdiv(npad * cout, 256)), dim3(256), 0, stream, a,
+    hipLaunchKernelGGL(conv_reduce_kernel, dim3((unsigned)cdiv(a.npad * a.cout, 256)), dim3(256), 0, stream, a,
                        p.nz);
     M3D_LAUNCH_CHECK();
   }
+  return M3D_OK;
+}
+
+static int check_schedule(const int32_t* d_nbr, const int32_t* d_out_row, const uint32_t* d_tile_mask, int k,
+                          int64_t n, int64_t* npad, const char* who) {
+  if (d_nbr == nullptr) {
+    if (!(k == 1 && d_out_row == nullptr && d_tile_mask == nullptr)) {
+      set_error("%s: dense mode needs k == 1 and no schedule", who);
+      return M3D_EINVAL;
+    }
+    *npad = m3d_schedule_npad(n);
+  } else {
+    if (!(d_out_row && d_tile_mask)) {
+      set_error("%s: schedule pointers missing", who);
+      return M3D_EINVAL;
+    }
+    if (!(*npad >= n && *npad % 128 == 0)) {
+      set_error("%s: npad=%lld must be a multiple of 128 >= n", who, (long long)*npad);
+      return M3D_EINVAL;
+    }
+  }
+  if (*npad >= (int64_t)1 << 31) {
+    set_error("%s: too many rows", who);
+    return M3D_EINVAL;
+  }
+  return M3D_OK;
+}
+
+extern "C" int m3d_conv_fwd_f32(const float* d_in0, int c0, const float* d_in1, int c1,
+                                const float* d_weight, int k, int cout, const int32_t* d_nbr,
+                                const int32_t* d_out_row, const uint32_t* d_tile_mask, int64_t n,
+                                int64_t npad, const float* d_scale, const float* d_shift,
+                                const float* d_residual, int relu, float* d_out, int64_t ldo,
+                                void* d_out_split, int out_terms, int precision, void* d_ws,
+                                size_t ws_bytes, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  const char* who = "m3d_conv_fwd_f32";
+  M3D_CHECK_ARG(n >= 0, "%s: n < 0", who);
+  if (n == 0) return M3D_OK;
+  M3D_CHECK_ARG(d_in0 && d_weight && (d_out || d_out_split), "%s: null pointer", who);
+  M3D_CHECK_ARG(c0 > 0 && c1 >= 0 && cout > 0 && k >= 1 && k <= 27, "%s: bad channel/kernel sizes", who);
+  M3D_CHECK_ARG((c1 == 0) == (d_in1 == nullptr), "%s: in1/c1 mismatch", who);
+  M3D_CHECK_ARG(d_out == nullptr || ldo >= cout, "%s: ldo < cout", who);
+  M3D_CHECK_ARG(precision >= 0 && precision <= 2, "%s: unknown precision %d", who, precision);
+  M3D_CHECK_ARG(d_out_split == nullptr || ((out_terms == 2 || out_terms == 3) && cout % 32 == 0),
+                "%s: a split output needs out_terms in {2,3} and cout %% 32 == 0", who);
+  if (int rc = check_schedule(d_nbr, d_out_row, d_tile_mask, k, n, &npad, who)) return rc;
+  ConvArgs a = {};
+  a.in0 = d_in0; a.in1 = d_in1; a.weight = d_weight; a.nbr = d_nbr; a.out_row = d_out_row;
+  a.tile_mask = d_tile_mask; a.scale = d_scale; a.shift = d_shift; a.residual = d_residual;
+  a.out = d_out; a.n = n; a.npad = npad; a.ldo = ldo; a.c0 = c0; a.c1 = c1;
+  a.cout = cout; a.kvol = k; a.relu = relu;
+  a.out_split = static_cast<char*>(d_out_split); a.terms = out_terms;
+  const bool mfma_ok = (c0 % 32 == 0) && (c1 % 32 == 0) && (cout % 32 == 0);
+  return run_conv(a, precision, mfma_ok, d_ws, ws_bytes, stream, who);
+}
+
+extern "C" int m3d_conv_fwd_sf32(const void* d_in0, int c0, int64_t rows0, const void* d_in1, int c1,
+                                 int64_t rows1, const void* d_weight, int k, int cout,
+                                 const int32_t* d_nbr, const int32_t* d_out_row,
+                                 const uint32_t* d_tile_mask, int64_t n, int64_t npad,
+                                 const float* d_scale, const float* d_shift, const float* d_residual,
+                                 int relu, float* d_out, int64_t ldo, void* d_out_split, int terms,
+                                 void* d_ws, size_t ws_bytes, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  const char* who = "m3d_conv_fwd_sf32";
+  M3D_CHECK_ARG(n >= 0, "%s: n < 0", who);
+  if (n == 0) return M3D_OK;
+  M3D_CHECK_ARG(d_in0 && d_weight && (d_out || d_out_split), "%s: null pointer", who);
+  M3D_CHECK_ARG(terms == 2 || terms == 3, "%s: terms must be 2 or 3", who);
+  M3D_CHECK_ARG(c0 > 0 && c1 >= 0 && cout > 0 && k >= 1 && k <= 27, "%s: bad channel/kernel sizes", who);
+  M3D_CHECK_ARG(c0 % 32 == 0 && c1 % 32 == 0 && cout % 32 == 0, "%s: channel counts must be multiples of 32", who);
+  M3D_CHECK_ARG((c1 == 0) == (d_in1 == nullptr), "%s: in1/c1 mismatch", who);
+  M3D_CHECK_ARG(rows0 >= 0 && rows1 >= 0, "%s: negative row count", who);
+  M3D_CHECK_ARG(d_out == nullptr || ldo >= cout, "%s: ldo < cout", who);
+  if (int rc = check_schedule(d_nbr, d_out_row, d_tile_mask, k, n, &npad, who)) return rc;
+  M3D_CHECK_ARG(d_nbr != nullptr || rows0 >= n, "%s: dense mode needs rows0 >= n", who);
+  ConvArgs a = {};
+  a.s0 = static_cast<const char*>(d_in0); a.s1 = static_cast<const char*>(d_in1);
+  a.zero0 = rows0; a.zero1 = rows1;
+  a.weight = static_cast<const float*>(d_weight); a.nbr = d_nbr; a.out_row = d_out_row;
+  a.tile_mask = d_tile_mask; a.scale = d_scale; a.shift = d_shift; a.residual = d_residual;
+  a.out = d_out; a.n = n; a.npad = npad; a.ldo = ldo; a.c0 = c0; a.c1 = c1;
+  a.cout = cout; a.kvol = k; a.relu = relu;
+  a.out_split = static_cast<char*>(d_out_split); a.terms = terms;
+  return run_conv(a, terms == 2 ? 3 : 4, true, d_ws, ws_bytes, stream, who);
+}
+
+extern "C" size_t m3d_sf32_bytes(int64_t n, int c, int terms) {
+  return (size_t)(n + 1) * (size_t)c * 2 * (size_t)terms;
+}
+
+extern "C" int m3d_split_f32(const float* d_in, int64_t n, int c, int terms, void* d_out, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  M3D_CHECK_ARG(d_in && d_out && n >= 0 && c > 0 && c % 32 == 0 && (terms == 2 || terms == 3),
+                "m3d_split_f32: bad arguments");
+  const int64_t total = (n + 1) * c;
+  hipLaunchKernelGGL(split_f32_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, stream, d_in, n, c, terms,
+                     static_cast<char*>(d_out));
+  M3D_LAUNCH_CHECK();
   return M3D_OK;
 }
 

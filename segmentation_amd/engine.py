@@ -64,6 +64,8 @@ class SpUNetEngine:
         sd = {k: v.detach().to("cpu") for k, v in sd.items()}
         self.cfg = cfg
         self.precision = precision
+        self._terms = {"f32": 0, "bf16x3": 2, "bf16x6": 3}[precision]
+        self.head_precision = "f32"  # the logits GEMM reads the f32 features the caller also receives
         self.device = torch.device(device)
         self.channels, self.layers = tuple(cfg["channels"]), tuple(cfg["layers"])
         self.num_stages = len(self.layers) // 2
@@ -111,7 +113,7 @@ class SpUNetEngine:
         cpad = 32 if c <= 32 else 64 if c <= 64 else 96 if c <= 96 else (c + 127) // 128 * 128
         w = torch.zeros((cpad, 1, d), dtype=torch.float32, device=self.device)
         w[:c, 0] = emb
-        self.text = _Conv(ops.pack_weight(w, self.precision), None, None)
+        self.text = _Conv(ops.pack_weight(w, self.head_precision), None, None)
         self.n_classes = c
         # folded head: logits = x96 . (E Wf)^T + E bf   (no nonlinearity between `final` and the head)
         wf = self._sd["final.weight"].reshape(self.final.cout, -1).double().to(self.device)
@@ -144,47 +146,61 @@ class SpUNetEngine:
         return levels
 
     # ------------------------------------------------------------------ network
-    def _block(self, blk, x, sched, n, x2=None):
+    # Activations travel as (f32 tensor or None, SplitTensor or None).  With precision "f32" only the f32
+    # member exists; with the split precisions convolutions consume the sf32 member through the LDS-DMA
+    # kernel and an f32 copy is written only where a residual or the caller needs it.
+    def _conv(self, c, x, sched, n, x2=None, residual=None, relu=False, need_f32=True, need_sf=True):
+        T = self._terms
+        if T == 0:
+            out = ops.conv_fwd(x[0], c.w, sched, n, in1=None if x2 is None else x2[0], scale=c.scale,
+                               shift=c.shift, residual=residual, relu=relu)
+            return (out, None)
+        if x[1] is not None and c.w.precision != "f32":
+            r = ops.conv_fwd(x[1], c.w, sched, n, in1=None if x2 is None else x2[1], scale=c.scale, shift=c.shift,
+                             residual=residual, relu=relu, want_f32=need_f32, split_terms=T if need_sf else 0)
+        else:  # f32 input (the 3-channel stem runs on the direct kernel)
+            r = ops.conv_fwd(x[0], c.w, sched, n, scale=c.scale, shift=c.shift, residual=residual, relu=relu,
+                             want_f32=need_f32, split_terms=T if need_sf else 0)
+        return r if need_sf else (r, None)
+
+    def _block(self, blk, x, sched, n, x2=None, last_needs_f32=True):
         """BasicBlock with fused epilogues; (x, x2) are the two K-slabs of a concatenated input."""
         if "proj" in blk:
-            p = blk["proj"]
-            res = ops.conv_fwd(x, p.w, None, n, in1=x2, scale=p.scale, shift=p.shift)
+            res = self._conv(blk["proj"], x, None, n, x2=x2, need_f32=True, need_sf=False)[0]
         else:
-            res = x
-        c1, c2 = blk["conv1"], blk["conv2"]
-        t = ops.conv_fwd(x, c1.w, sched, n, in1=x2, scale=c1.scale, shift=c1.shift, relu=True)
-        return ops.conv_fwd(t, c2.w, sched, n, scale=c2.scale, shift=c2.shift, residual=res, relu=True)
+            res = x[0]
+        t = self._conv(blk["conv1"], x, sched, n, x2=x2, relu=True, need_f32=self._terms == 0)
+        return self._conv(blk["conv2"], t, sched, n, residual=res, relu=True, need_f32=True)
 
     def backbone(self, voxel_feats, levels, keep=None):
-        """SpUNetBase.forward after sparsify (v1m3:388-407).  Returns [N0, out_channels]."""
+        """SpUNetBase.forward after sparsify (v1m3:388-407).  Returns the activation pair of the last decoder
+        block ([N0, channels[-1]])."""
         ns = self.num_stages
         l0 = levels[0]
-        x = ops.conv_fwd(voxel_feats, self.stem.w, l0.subm, l0.n, scale=self.stem.scale,
-                         shift=self.stem.shift, relu=True)
+        f32_only = self._terms == 0
+        x = self._conv(self.stem, (voxel_feats, None), l0.subm, l0.n, relu=True, need_f32=f32_only or keep is not None)
         if keep is not None:
-            keep["conv_input"] = x
+            keep["conv_input"] = x[0]
         skips = [x]
         for s in range(ns):
-            d = self.down[s]
-            x = ops.conv_fwd(x, d.w, levels[s].down, levels[s + 1].n, scale=d.scale, shift=d.shift, relu=True)
+            x = self._conv(self.down[s], x, levels[s].down, levels[s + 1].n, relu=True, need_f32=True)
             if keep is not None:
-                keep[f"down.{s}"] = x
+                keep[f"down.{s}"] = x[0]
             for blk in self.enc[s]:
                 x = self._block(blk, x, levels[s + 1].subm, levels[s + 1].n)
             if keep is not None:
-                keep[f"enc.{s}"] = x
+                keep[f"enc.{s}"] = x[0]
             skips.append(x)
         x = skips.pop(-1)
         for s in reversed(range(ns)):
-            u = self.up[s]
-            x = ops.conv_fwd(x, u.w, levels[s].up, levels[s].n, scale=u.scale, shift=u.shift, relu=True)
+            x = self._conv(self.up[s], x, levels[s].up, levels[s].n, relu=True, need_f32=f32_only or keep is not None)
             if keep is not None:
-                keep[f"up.{s}"] = x
+                keep[f"up.{s}"] = x[0]
             skip = skips.pop(-1)
             for i, blk in enumerate(self.dec[s]):
                 x = self._block(blk, x, levels[s].subm, levels[s].n, x2=skip if i == 0 else None)
             if keep is not None:
-                keep[f"dec.{s}"] = x
+                keep[f"dec.{s}"] = x[0]
         return x
 
     def forward_features(self, coord, feat, offset, grid_size, keep=None):
@@ -192,8 +208,7 @@ class SpUNetEngine:
         vox = ops.voxelize(coord, feat, offset, grid_size, pad=128)
         levels = self.build_levels(vox["voxel_coords"], vox["spatial_shape"], vox["batch_size"])
         x = self.backbone(vox["voxel_feats"], levels, keep)
-        f = self.final
-        out = ops.conv_fwd(x, f.w, None, x.shape[0], shift=f.shift)
+        out = self._conv(self.final, x, None, levels[0].n, need_f32=True, need_sf=False)[0]
         if keep is not None:
             keep["final"] = out
             keep["levels"] = levels
@@ -210,7 +225,8 @@ class SpUNetEngine:
             levels = self.build_levels(vox["voxel_coords"], vox["spatial_shape"], vox["batch_size"])
             x = self.backbone(vox["voxel_feats"], levels)
             t = self.text_folded
-            logits = ops.conv_fwd(x, t.w, None, x.shape[0], shift=t.shift, flop_cout=self.n_classes)
+            src = x[1] if self._terms else x[0]
+            logits = ops.conv_fwd(src, t.w, None, levels[0].n, shift=t.shift, flop_cout=self.n_classes)
             self.last_stats = dict(n_points=int(coord.shape[0]), n_voxels=[lv.n for lv in levels])
         else:
             feats, vox = self.forward_features(coord, feat, offset, grid_size)

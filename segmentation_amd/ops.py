@@ -216,31 +216,85 @@ def pack_weight(weight, precision="f32", device=None):
     return PackedWeight(out, k, cout, cin, precision)
 
 
+@dataclass
+class SplitTensor:
+    """An f32 [n, c] tensor in the engine-internal split format "sf32" (see include/m3d.h):
+    [n + 1][c/32][terms][32] bf16, row n all zero."""
+    data: torch.Tensor  # uint8
+    n: int
+    c: int
+    terms: int
+
+    @property
+    def shape(self):
+        return (self.n, self.c)
+
+
+def split_f32(x, terms):
+    lib = _lib.load()
+    _need_cuda(x)
+    x = x.contiguous().float()
+    n, c = x.shape
+    out = torch.empty((lib.m3d_sf32_bytes(n, c, terms),), dtype=torch.uint8, device=x.device)
+    rc = lib.m3d_split_f32(_ptr(x), n, c, terms, _ptr(out), _stream())
+    _lib.check(rc, "m3d_split_f32")
+    return SplitTensor(out, n, c, terms)
+
+
+def unsplit(st: SplitTensor):
+    """sf32 -> f32 (sum of the terms); for tests and debugging."""
+    v = st.data.view(torch.bfloat16).view(st.n + 1, st.c // 32, st.terms, 32).float().sum(2)
+    return v.reshape(st.n + 1, st.c)[:st.n]
+
+
 def conv_fwd(in0, weight_packed: PackedWeight, sched: Optional[Schedule], n_out, in1=None, scale=None, shift=None,
-             residual=None, relu=False, out=None, flop_cout=None):
+             residual=None, relu=False, out=None, flop_cout=None, want_f32=True, split_terms=0):
     """out[row] = act(scale * sum_k W[k] . cat(in0, in1)[nbr[k][t]] + shift + residual[row]).
 
-    sched=None is the dense 1x1 case (Custom1x1Subm3d, structure.py:336-347)."""
+    sched=None is the dense 1x1 case (Custom1x1Subm3d, structure.py:336-347).  in0/in1 are f32 tensors or
+    SplitTensors (then the LDS-DMA kernel runs; the weight must be packed for the matching precision).
+    Returns the f32 output, or (f32 output or None, SplitTensor) when split_terms is 2 or 3."""
     lib = _lib.load()
-    _need_cuda(in0, weight_packed.data)
+    sf_in = isinstance(in0, SplitTensor)
     k, cout, cin = weight_packed.k, weight_packed.cout, weight_packed.cin
     c0 = in0.shape[1]
     c1 = 0 if in1 is None else in1.shape[1]
     if c0 + c1 != cin:
         raise ValueError(f"input channels {c0}+{c1} do not match the weight's {cin}")
-    assert in0.is_contiguous() and in0.dtype == torch.float32
-    assert in1 is None or (in1.is_contiguous() and in1.dtype == torch.float32)
-    dev = in0.device
-    if out is None:
+    if sf_in:
+        want = {2: "bf16x3", 3: "bf16x6"}[in0.terms]
+        if weight_packed.precision != want:
+            raise ValueError(f"sf32 input with {in0.terms} terms needs a weight packed for {want}")
+        if in1 is not None and not (isinstance(in1, SplitTensor) and in1.terms == in0.terms):
+            raise ValueError("both inputs must use the same split format")
+        dev = in0.data.device
+        _need_cuda(in0.data, weight_packed.data)
+    else:
+        _need_cuda(in0, weight_packed.data)
+        assert in0.is_contiguous() and in0.dtype == torch.float32
+        assert in1 is None or (in1.is_contiguous() and in1.dtype == torch.float32)
+        dev = in0.device
+    if split_terms not in (0, 2, 3):
+        raise ValueError("split_terms must be 0, 2 or 3")
+    if sf_in and split_terms and split_terms != in0.terms:
+        raise ValueError("the split output of an sf32 convolution uses the input's number of terms")
+    if not want_f32 and split_terms == 0:
+        raise ValueError("nothing to compute: want_f32=False and split_terms=0")
+    if out is None and want_f32:
         out = torch.empty((n_out, cout), dtype=torch.float32, device=dev)
-    assert out.dtype == torch.float32 and out.shape[0] == n_out and out.shape[1] >= cout and out.stride(1) == 1
-    ldo = out.stride(0)
+    if out is not None:
+        assert out.dtype == torch.float32 and out.shape[0] == n_out and out.shape[1] >= cout and out.stride(1) == 1
+    ldo = out.stride(0) if out is not None else cout
+    out_sp = None
+    if split_terms:
+        out_sp = SplitTensor(torch.empty((lib.m3d_sf32_bytes(n_out, cout, split_terms),), dtype=torch.uint8, device=dev),
+                             n_out, cout, split_terms)
     for v in (scale, shift):
         assert v is None or (v.is_contiguous() and v.dtype == torch.float32 and v.numel() == cout)
     if residual is not None:
         assert residual.is_contiguous() and residual.shape == (n_out, cout) and residual.dtype == torch.float32
     if n_out == 0:
-        return out
+        return out if not split_terms else (out, out_sp)
     if sched is None:
         if k != 1:
             raise ValueError("a convolution without a schedule must have one kernel offset")
@@ -266,16 +320,25 @@ def conv_fwd(in0, weight_packed: PackedWeight, sched: Optional[Schedule], n_out,
         mfma = c0 % 32 == 0 and c1 % 32 == 0 and cout % 32 == 0
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
-    rc = lib.m3d_conv_fwd_f32(_ptr(in0), c0, _ptr(in1), c1, _ptr(weight_packed.data), k, cout, _ptr(nbr),
-                              _ptr(orow), _ptr(mask), n_out, npad, _ptr(scale), _ptr(shift),
-                              _ptr(residual), int(bool(relu)), _ptr(out), ldo,
-                              PRECISION[weight_packed.precision], _ptr(ws), ws.numel(), _stream())
-    _lib.check(rc, "m3d_conv_fwd_f32")
+    osp = None if out_sp is None else out_sp.data
+    if sf_in:
+        rc = lib.m3d_conv_fwd_sf32(_ptr(in0.data), c0, in0.n, _ptr(None if in1 is None else in1.data), c1,
+                                   0 if in1 is None else in1.n, _ptr(weight_packed.data), k, cout, _ptr(nbr),
+                                   _ptr(orow), _ptr(mask), n_out, npad, _ptr(scale), _ptr(shift), _ptr(residual),
+                                   int(bool(relu)), _ptr(out), ldo, _ptr(osp), in0.terms,
+                                   _ptr(ws), ws.numel(), _stream())
+        _lib.check(rc, "m3d_conv_fwd_sf32")
+    else:
+        rc = lib.m3d_conv_fwd_f32(_ptr(in0), c0, _ptr(in1), c1, _ptr(weight_packed.data), k, cout, _ptr(nbr),
+                                  _ptr(orow), _ptr(mask), n_out, npad, _ptr(scale), _ptr(shift),
+                                  _ptr(residual), int(bool(relu)), _ptr(out), ldo, _ptr(osp), split_terms,
+                                  PRECISION[weight_packed.precision], _ptr(ws), ws.numel(), _stream())
+        _lib.check(rc, "m3d_conv_fwd_f32")
     if prof is not None:
         ev1.record()
-        prof.append(("igemm" if mfma else "direct", 2.0 * npairs * cin * (flop_cout or cout), ev0, ev1,
-                     (n_out, cin, cout, k)))
-    return out
+        kind = ("dma" if sf_in else "igemm") if mfma else "direct"
+        prof.append((kind, 2.0 * npairs * cin * (flop_cout or cout), ev0, ev1, (n_out, cin, cout, k)))
+    return out if not split_terms else (out, out_sp)
 
 
 # ----------------------------------------------------------------------------- head

@@ -1,0 +1,130 @@
+"""The LDS-DMA convolution on split-format (sf32) activations (m3d_conv_fwd_sf32, m3d_split_f32) against the
+CPU oracle.  Tolerances: terms=3 (bf16x6) 1e-5, terms=2 (bf16x3) 6e-5 per-row relative L2, one layer."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from segmentation_amd import ops, scenes
+
+pytestmark = pytest.mark.gpu
+TOL = {3: 1e-5, 2: 6e-5}
+PREC = {3: "bf16x6", 2: "bf16x3"}
+
+
+def _rel(out, ref):
+    ref = ref.double()
+    return ((out.double().cpu() - ref).norm(dim=1) / ref.norm(dim=1).clamp_min(1e-12)).max().item()
+
+
+@pytest.fixture(scope="module")
+def level(device):
+    sc = scenes.make_scene(seed=4, target_voxels=12000)
+    off = np.array([0, sc["coord"].shape[0]], dtype=np.int64)
+    sp = oracle.sparsify(sc["coord"], sc["feat"], off, 0.02)
+    idx = torch.from_numpy(sp["voxel_coords"]).to(device)
+    pair = ops.subm_rulebook(idx, sp["spatial_shape"])
+    sched = ops.build_schedule(pair, idx.shape[0], idx, 1, sp["spatial_shape"], 1)
+    oi, oshape, pf, pb = ops.strided_rulebook(idx, sp["spatial_shape"], 1)
+    return dict(sp=sp, idx=idx, pair=pair.cpu().numpy(), sched=sched, oi=oi, pf=pf, pb=pb,
+                sched_down=ops.build_schedule(pf, oi.shape[0], None, 0),
+                sched_up=ops.build_schedule(pb, idx.shape[0], None, 2, base_order=sched.out_row))
+
+
+@pytest.mark.parametrize("terms", [2, 3])
+def test_split_roundtrip(device, terms):
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(1000, 96, generator=g) * torch.logspace(-6, 6, 96)
+    st = ops.split_f32(x.to(device), terms)
+    back = ops.unsplit(st).cpu()
+    tol = 2.0 ** -16 if terms == 2 else 2.0 ** -23
+    assert ((back - x).abs() <= tol * x.abs()).all()
+    raw = st.data.view(torch.bfloat16).view(1001, 3, terms, 32)
+    assert (raw[1000] == 0).all()  # the zero row
+
+
+@pytest.mark.parametrize("terms", [2, 3])
+@pytest.mark.parametrize("cin,cout", [(32, 32), (64, 64), (96, 96), (128, 96), (128, 128), (256, 256), (384, 256)])
+def test_subm_conv(device, level, cin, cout, terms):
+    g = torch.Generator().manual_seed(cin * 1000 + cout)
+    n = level["idx"].shape[0]
+    x = torch.randn(n, cin, generator=g)
+    w = torch.randn(cout, 3, 3, 3, cin, generator=g) / np.sqrt(9 * cin)
+    ref = oracle.subm_conv(x, w, level["pair"])
+    out = ops.conv_fwd(ops.split_f32(x.to(device), terms), ops.pack_weight(w, PREC[terms], device), level["sched"], n)
+    assert _rel(out, ref) < TOL[terms]
+
+
+@pytest.mark.parametrize("terms", [2, 3])
+def test_fused_epilogue_two_sources_and_split_output(device, level, terms):
+    g = torch.Generator().manual_seed(7)
+    n = level["idx"].shape[0]
+    xa, xb = torch.randn(n, 96, generator=g), torch.randn(n, 32, generator=g)
+    w = torch.randn(96, 3, 3, 3, 128, generator=g) / np.sqrt(9 * 128)
+    scale, shift = torch.rand(96, generator=g) + 0.5, torch.randn(96, generator=g)
+    res = torch.randn(n, 96, generator=g)
+    ref = torch.relu(oracle.subm_conv(torch.cat((xa, xb), 1), w, level["pair"]) * scale + shift + res)
+    out, osp = ops.conv_fwd(ops.split_f32(xa.to(device), terms), ops.pack_weight(w, PREC[terms], device), level["sched"],
+                            n, in1=ops.split_f32(xb.to(device), terms), scale=scale.to(device), shift=shift.to(device),
+                            residual=res.to(device), relu=True, split_terms=terms)
+    assert _rel(out, ref) < TOL[terms]
+    # the split copy is the same tensor in sf32, zero row included
+    back = ops.unsplit(osp)
+    tol = 2.0 ** -16 if terms == 2 else 2.0 ** -23
+    assert ((back - out).abs() <= tol * out.abs()).all()
+    raw = osp.data.view(torch.bfloat16).view(n + 1, 3, terms, 32)
+    assert (raw[n] == 0).all()
+    # split-only output
+    none, osp2 = ops.conv_fwd(ops.split_f32(xa.to(device), terms), ops.pack_weight(w, PREC[terms], device),
+                              level["sched"], n, in1=ops.split_f32(xb.to(device), terms), scale=scale.to(device),
+                              shift=shift.to(device), residual=res.to(device), relu=True, want_f32=False,
+                              split_terms=terms)
+    assert none is None and torch.equal(osp2.data, osp.data)
+
+
+@pytest.mark.parametrize("terms", [2, 3])
+@pytest.mark.parametrize("cin,cout", [(32, 64), (128, 256)])
+def test_strided_and_inverse(device, level, cin, cout, terms):
+    g = torch.Generator().manual_seed(cin + cout)
+    n, m = level["idx"].shape[0], level["oi"].shape[0]
+    x = torch.randn(n, cin, generator=g)
+    w = torch.randn(cout, 2, 2, 2, cin, generator=g) / np.sqrt(8 * cin)
+    ref = oracle.strided_conv(x, w, level["pf"].cpu().numpy())
+    out = ops.conv_fwd(ops.split_f32(x.to(device), terms), ops.pack_weight(w, PREC[terms], device), level["sched_down"], m)
+    assert _rel(out, ref) < TOL[terms]
+    y = torch.randn(m, cout, generator=g)
+    wi = torch.randn(cin, 2, 2, 2, cout, generator=g) / np.sqrt(cout)
+    ref_i = oracle.inverse_conv(y, wi, level["pb"].cpu().numpy())
+    out_i = ops.conv_fwd(ops.split_f32(y.to(device), terms), ops.pack_weight(wi, PREC[terms], device), level["sched_up"], n)
+    assert _rel(out_i, ref_i) < TOL[terms]
+
+
+@pytest.mark.parametrize("terms", [2, 3])
+@pytest.mark.parametrize("n,cin,cout", [(5000, 96, 768), (700, 384, 256), (130, 128, 96), (1, 96, 32), (70000, 128, 96)])
+def test_dense_1x1(device, n, cin, cout, terms):
+    g = torch.Generator().manual_seed(n)
+    x = torch.randn(n, cin, generator=g)
+    w = torch.randn(cout, 1, 1, 1, cin, generator=g) / np.sqrt(cin)
+    b = torch.randn(cout, generator=g)
+    ref = oracle.conv1x1(x, w, b)
+    out = ops.conv_fwd(ops.split_f32(x.to(device), terms), ops.pack_weight(w, PREC[terms], device), None, n, shift=b.to(device))
+    assert _rel(out, ref) < TOL[terms]
+
+
+@pytest.mark.parametrize("terms", [2, 3])
+@pytest.mark.parametrize("target", [300, 1500, 30000])
+def test_all_tile_configurations(device, target, terms):
+    sc = scenes.make_scene(seed=9, target_voxels=target)
+    off = np.array([0, sc["coord"].shape[0]], dtype=np.int64)
+    sp = oracle.sparsify(sc["coord"], sc["feat"], off, 0.02)
+    idx = torch.from_numpy(sp["voxel_coords"]).to(device)
+    n = idx.shape[0]
+    pair = ops.subm_rulebook(idx, sp["spatial_shape"])
+    sched = ops.build_schedule(pair, n, idx, 1, sp["spatial_shape"], 1)
+    for cin, cout in [(32, 32), (64, 64), (96, 96), (128, 128), (256, 256)]:
+        g = torch.Generator().manual_seed(cin)
+        x = torch.randn(n, cin, generator=g)
+        w = torch.randn(cout, 3, 3, 3, cin, generator=g) / np.sqrt(9 * cin)
+        ref = oracle.subm_conv(x, w, pair.cpu().numpy())
+        out = ops.conv_fwd(ops.split_f32(x.to(device), terms), ops.pack_weight(w, PREC[terms], device), sched, n)
+        assert _rel(out, ref) < TOL[terms], (target, cin, cout)
