@@ -491,11 +491,12 @@ struct DmaGeom {
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 template <int WM, int WN, int NT, int T>
-__global__ __launch_bounds__(64 * WM * WN) void conv_igemm_dma_kernel(ConvArgs a) {
+__device__ __forceinline__ void conv_igemm_dma_body(const ConvArgs& a) {
   using G = DmaGeom<T>;
   constexpr int BM = 32 * WM, BN = 32 * NT * WN, NTHR = 64 * WM * WN;
   constexpr int A_BYTES = BM * G::ROWB, W_BYTES = BN * G::ROWB, BUF = A_BYTES + W_BYTES;
   constexpr int A_V = BM * G::SLOTS / NTHR, W_V = BN * G::SLOTS / NTHR;
+  constexpr int GRPB = G::PIECES * 16;  // bytes of one (row, 32-channel group) in HBM
   static_assert(BM * G::SLOTS % NTHR == 0 && BN * G::SLOTS % NTHR == 0, "every wave must issue the same DMA count");
   extern __shared__ __align__(16) char ldsb[];
   int* idx_s = reinterpret_cast<int*>(ldsb + 2 * BUF);  // [kvol][BM]
@@ -506,11 +507,10 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_dma_kernel(ConvArgs a
   const int wm = wave / WN, wn = wave % WN;
   const int64_t tile_base = xcd_tile(blockIdx.x, gridDim.x) * BM;
   const int col_base = blockIdx.y * BN;
-  const int cin = a.c0 + a.c1;
-  const int nchunk = cin / kBK;
+  const int nchunk = (a.c0 + a.c1) / kBK;
   const int g0 = a.c0 / kBK;
   const char* wsplit = reinterpret_cast<const char*>(a.weight);
-  const int64_t rowb0 = (int64_t)g0 * (G::PIECES * 16), rowb1 = (int64_t)(a.c1 / kBK) * (G::PIECES * 16);
+  const uint32_t rowb0 = (uint32_t)g0 * GRPB, rowb1 = (uint32_t)(a.c1 / kBK) * GRPB;
 
   uint32_t bmask, wmask;
   conv_masks<WM>(a, tile_base, wm, bmask, wmask);
@@ -534,106 +534,143 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_dma_kernel(ConvArgs a
 
   const int nstage = __popc(bmask) * nchunk;
 
-  // this thread's slots: e = v * NTHR + tid -> (row, physical slot p'), logical piece p = p' ^ swz(row)
-  auto issue = [&](int k, int cc, int buf) {
-    const char* src;
-    int64_t rowb, zero;
-    int grp;
-    if (cc < g0) { src = a.s0; rowb = rowb0; zero = a.zero0; grp = cc; }
-    else { src = a.s1; rowb = rowb1; zero = a.zero1; grp = cc - g0; }
-    char* Ab = ldsb + buf * BUF;
+  // Loop-invariant per-thread addressing.  Slot e = v * NTHR + tid of a buffer is (row e / SLOTS, physical
+  // slot e % SLOTS) and carries logical piece p = slot ^ swz(row).
+  int a_r[A_V];
+  uint32_t a_p[A_V];
+  bool a_on[A_V];
+#pragma unroll
+  for (int v = 0; v < A_V; ++v) {
+    const int e = v * NTHR + tid;
+    a_r[v] = e / G::SLOTS;
+    const int p = (e % G::SLOTS) ^ G::swz(a_r[v]);
+    a_p[v] = (uint32_t)p * 16u;
+    a_on[v] = T == 2 || p < G::PIECES;
+  }
+  uint32_t w_o[W_V];
+  bool w_on[W_V];
+#pragma unroll
+  for (int v = 0; v < W_V; ++v) {
+    const int e = v * NTHR + tid;
+    const int j = e / G::SLOTS;
+    const int p = (e % G::SLOTS) ^ G::swz(j);
+    w_o[v] = (uint32_t)((col_base + j) * nchunk) * GRPB + (uint32_t)p * 16u;
+    w_on[v] = T == 2 || p < G::PIECES;
+  }
+  const uint32_t wk_stride = (uint32_t)(a.cout * nchunk) * GRPB;  // bytes of one kernel offset's weights
+  // Issue iterator: (ik, icc) is the next stage to request, a_id the gathered rows of kernel offset ik.
+  // (Lambdas here are only ever called from the kernel body itself, never from one another.)
+  int a_id[A_V];
+  uint32_t rem = bmask;
+  int ik = bmask ? __builtin_ctz(bmask) : 0, icc = 0, issued = 0;
+#pragma unroll
+  for (int v = 0; v < A_V; ++v) a_id[v] = idx_s[ik * BM + a_r[v]];
+  auto issue_next = [&](int bi) {
+    char* buf = ldsb + bi * BUF;
+    const bool first = icc < g0;
+    const char* src = (first ? a.s0 : a.s1) + (first ? icc : icc - g0) * GRPB;
+    const uint32_t rowb = first ? rowb0 : rowb1;
+    const int zero = (int)(first ? a.zero0 : a.zero1);
 #pragma unroll
     for (int v = 0; v < A_V; ++v) {
-      const int e = v * NTHR + tid;
-      const int r = e / G::SLOTS, p = (e % G::SLOTS) ^ G::swz(r);
-      int id = idx_s[k * BM + r];
-      const int64_t row = id < 0 ? zero : (int64_t)id;
-      const char* g = src + row * rowb + grp * (G::PIECES * 16) + p * 16;
-      if (T == 2 || p < G::PIECES)
-        __builtin_amdgcn_global_load_lds(g, (lds_ptr_t)(Ab + (v * NTHR + wave * 64) * 16), 16, 0, 0);
+      const uint32_t row = (uint32_t)(a_id[v] < 0 ? zero : a_id[v]);
+      const char* g = src + ((uint64_t)row * rowb + a_p[v]);
+      if (a_on[v]) __builtin_amdgcn_global_load_lds(g, (lds_ptr_t)(buf + (v * NTHR + wave * 64) * 16), 16, 0, 0);
     }
-    char* Wb = Ab + A_BYTES;
+    const char* wsrc = wsplit + ((uint64_t)ik * wk_stride + (uint32_t)icc * GRPB);
 #pragma unroll
-    for (int v = 0; v < W_V; ++v) {
-      const int e = v * NTHR + tid;
-      const int j = e / G::SLOTS, p = (e % G::SLOTS) ^ G::swz(j);
-      const char* g = wsplit + (((int64_t)k * a.cout + col_base + j) * nchunk + cc) * (G::PIECES * 16) + p * 16;
-      if (T == 2 || p < G::PIECES)
-        __builtin_amdgcn_global_load_lds(g, (lds_ptr_t)(Wb + (v * NTHR + wave * 64) * 16), 16, 0, 0);
+    for (int v = 0; v < W_V; ++v)
+      if (w_on[v])
+        __builtin_amdgcn_global_load_lds(wsrc + w_o[v], (lds_ptr_t)(buf + A_BYTES + (v * NTHR + wave * 64) * 16), 16, 0, 0);
+    ++issued;
+    if (++icc == nchunk) {
+      icc = 0;
+      rem &= rem - 1;
+      if (rem) {
+        ik = __builtin_ctz(rem);
+#pragma unroll
+        for (int v = 0; v < A_V; ++v) a_id[v] = idx_s[ik * BM + a_r[v]];
+      }
+    }
+  };
+
+  // fragment addresses (loop invariant): row of A / W this lane reads, with the swizzle applied per piece
+  const int r32 = lane & 31, h = lane >> 5;
+  const int arow = wm * 32 + r32;
+  uint32_t a_off[2][T], w_off[NT][2][T];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      a_off[ks][t] = arow * G::ROWB + (((t * 4 + ks * 2 + h) ^ G::swz(arow)) * 16);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int j = (wn * NT + nt) * 32 + r32;
+        w_off[nt][ks][t] = A_BYTES + j * G::ROWB + (((t * 4 + ks * 2 + h) ^ G::swz(j)) * 16);
+      }
+    }
+
+  auto compute = [&](int bi) {
+    const char* buf = ldsb + bi * BUF;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 af[T];
+#pragma unroll
+      for (int t = 0; t < T; ++t) af[t] = *reinterpret_cast<const bf16x8*>(buf + a_off[ks][t]);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        bf16x8 bf[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) bf[t] = *reinterpret_cast<const bf16x8*>(buf + w_off[nt][ks][t]);
+        if (T == 3) {
+          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[T - 1], acc[nt], 0, 0, 0);
+          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[T - 1], bf[0], acc[nt], 0, 0, 0);
+          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[1], acc[nt], 0, 0, 0);
+        }
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[1], acc[nt], 0, 0, 0);
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[0], acc[nt], 0, 0, 0);
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[0], acc[nt], 0, 0, 0);
+      }
     }
   };
 
   if (nstage > 0) {
-    // stage iterator (k, cc) for issue, advanced one stage at a time
-    uint32_t rem = bmask;
-    int ik = __builtin_ctz(rem), icc = 0;
-    auto advance = [&]() {
-      if (++icc == nchunk) {
-        icc = 0;
-        rem &= rem - 1;
-        ik = rem ? __builtin_ctz(rem) : ik;
-      }
-    };
-    issue(ik, icc, 0);
-    advance();
-    if (nstage > 1) {
-      issue(ik, icc, 1);
-      advance();
-    }
+    issue_next(0);
+    if (nstage > 1) issue_next(1);
     uint32_t crem = bmask;
     int ck = __builtin_ctz(crem), ccc = 0;
-    const int r32 = lane & 31, h = lane >> 5;
-    const int arow = wm * 32 + r32;
-    for (int s = 0; s < nstage; ++s) {
-      if (s + 1 < nstage) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_V + W_V) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-      if ((wmask >> ck) & 1u) {
-        const char* Ab = ldsb + (s & 1) * BUF + arow * G::ROWB;
-        const char* Wb = ldsb + (s & 1) * BUF + A_BYTES;
-        const int asw = G::swz(arow);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          bf16x8 af[T];
-#pragma unroll
-          for (int t = 0; t < T; ++t)
-            af[t] = *reinterpret_cast<const bf16x8*>(Ab + (((t * 4 + ks * 2 + h) ^ asw) * 16));
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt) {
-            const int j = (wn * NT + nt) * 32 + r32;
-            const int jsw = G::swz(j);
-            bf16x8 bf[T];
-#pragma unroll
-            for (int t = 0; t < T; ++t)
-              bf[t] = *reinterpret_cast<const bf16x8*>(Wb + j * G::ROWB + (((t * 4 + ks * 2 + h) ^ jsw) * 16));
-            if (T == 3) {
-              acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[T - 1], acc[nt], 0, 0, 0);
-              acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[T - 1], bf[0], acc[nt], 0, 0, 0);
-              acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[1], acc[nt], 0, 0, 0);
-            }
-            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[1], acc[nt], 0, 0, 0);
-            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[0], acc[nt], 0, 0, 0);
-            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[0], acc[nt], 0, 0, 0);
-          }
-        }
-      }
-      if (++ccc == nchunk) {
-        ccc = 0;
-        crem &= crem - 1;
-        ck = crem ? __builtin_ctz(crem) : ck;
-      }
-      // every wave has consumed buffer (s & 1): refill it with stage s + 2
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-      if (s + 2 < nstage) {
-        issue(ik, icc, s & 1);
-        advance();
-      }
+// one step: stage S lives in buffer BI; afterwards the buffer is refilled with stage S + 2
+#define M3D_DMA_STEP(S, BI)                                                                   \
+  {                                                                                           \
+    if ((S) + 1 < nstage) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_V + W_V) : "memory");    \
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                     \
+    __builtin_amdgcn_s_barrier();                                                             \
+    asm volatile("" ::: "memory");                                                            \
+    if ((wmask >> ck) & 1u) compute(BI);                                                      \
+    if (++ccc == nchunk) {                                                                    \
+      ccc = 0;                                                                                \
+      crem &= crem - 1;                                                                       \
+      ck = crem ? __builtin_ctz(crem) : ck;                                                   \
+    }                                                                                         \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                        \
+    __builtin_amdgcn_s_barrier();                                                             \
+    asm volatile("" ::: "memory");                                                            \
+    if (issued < nstage) issue_next(BI);                                                      \
+  }
+    int s = 0;
+    for (; s + 1 < nstage; s += 2) {
+      M3D_DMA_STEP(s, 0)
+      M3D_DMA_STEP(s + 1, 1)
     }
+    if (s < nstage) M3D_DMA_STEP(s, 0)
+#undef M3D_DMA_STEP
   }
   conv_epilogue<NT>(a, acc, orow_s, tile_base, col_base, wm, wn, lane);
+}
+
+template <int WM, int WN, int NT, int T>
+__global__ __launch_bounds__(64 * WM * WN) void conv_igemm_dma_kernel(ConvArgs a) {
+  conv_igemm_dma_body<WM, WN, NT, T>(a);
 }
 
 // f32 [n][c] -> sf32 [n + 1][c/32][terms][32] bf16 (row n zero).  One thread per element.

@@ -14,6 +14,9 @@ pair = ops.subm_rulebook(idx, vox["spatial_shape"])
 sched = ops.build_schedule(pair, N, idx, 1, vox["spatial_shape"], 1)
 x = torch.randn(N, cin, device=dev); w = ops.pack_weight(torch.randn(cout, 27, cin) * 0.03, prec, dev)
 xd = torch.randn(N, 768, device=dev); wd = ops.pack_weight(torch.randn(256, 1, 768) * 0.03, prec, dev)
+if len(sys.argv) > 2 and sys.argv[2] == "dma":
+    T = {"bf16x3": 2, "bf16x6": 3}[prec]
+    x, xd = ops.split_f32(x, T), ops.split_f32(xd, T)
 def t(fn, reps=5):
     fn(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -21,8 +24,8 @@ def t(fn, reps=5):
     for _ in range(reps): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps * 1e3
-for dbg, name in [(0, "full"), (1, "no MFMA"), (2, "no A loads"), (4, "no W loads"), (6, "no A,W loads"), (8, "no commit"),
-                  (16 | 2, "no idx, no A"), (1 | 8, "no MFMA, no commit"), (1 | 2 | 4 | 8 | 16, "skeleton")]:
+for dbg, name in [(0, "full"), (1, "no MFMA"), (2, "no A loads"), (4, "no W loads"), (6, "no A,W loads"),
+                  (1 | 2, "no MFMA, no A"), (1 | 4, "no MFMA, no W"), (1 | 2 | 4, "skeleton")]:
     os.environ["M3D_DBG"] = str(dbg)
     a = t(lambda: ops.conv_fwd(x, w, sched, N))
     b = t(lambda: ops.conv_fwd(xd, wd, None, N))
