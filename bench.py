@@ -23,12 +23,18 @@ import numpy as np
 import torch
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X dense f32 matrix peak (v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD)
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X dense bf16 matrix peak
+# algorithmic-FLOP peak of the convolution kernel per precision: the split paths spend 3 (6) bf16 MFMA
+# products per f32 product
+PEAK = {"f32": PEAK_F32_MFMA_TFLOPS, "bf16x3": PEAK_BF16_MFMA_TFLOPS / 3, "bf16x6": PEAK_BF16_MFMA_TFLOPS / 6}
+DTYPE = {"f32": "f32", "bf16x3": "f32 (products: 3x bf16 MFMA on 2-term splits, f32 accumulate)",
+         "bf16x6": "f32 (products: 6x bf16 MFMA on 3-term splits, f32 accumulate)"}
 GRID = 0.02
 N_CLASSES = 200
 TARGET_VOXELS = 290_000        # scene-generator target; lands at ~250 k occupied 2 cm voxels
 
 
-def build_engine(device, precision="f32"):
+def build_engine(device, precision="bf16x3"):
     from segmentation_amd import spunet
     from segmentation_amd.engine import SpUNetEngine
     from segmentation_amd import scenes
@@ -70,7 +76,8 @@ def main():
     ap.add_argument("--target-voxels", type=int, default=TARGET_VOXELS)
     ap.add_argument("--scenes-per-rank", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--precision", default="f32", choices=["f32", "bf16x6", "bf16x3"])
+    ap.add_argument("--precision", default="bf16x3", choices=["f32", "bf16x6", "bf16x3"],
+                    help="how f32 products are formed: exact f32 MFMA, or bf16 MFMA on 3-/2-term splits")
     ap.add_argument("--fold-head", action="store_true", help="fold `final` into the text matrix (not the headline)")
     args = ap.parse_args()
 
@@ -135,7 +142,7 @@ def main():
     elapsed, nvox_all = sharding.reduce_job(elapsed, float(nvox), dist, device)
 
     if rank == 0:
-        ig = [(f, e0.elapsed_time(e1) * 1e-3) for kind, f, e0, e1, _ in prof if kind == "igemm"]
+        ig = [(f, e0.elapsed_time(e1) * 1e-3) for kind, f, e0, e1, _ in prof if kind in ("igemm", "dma")]
         flops = sum(f for f, _ in ig)
         secs = sum(t for _, t in ig)
         nl = max(len(ig), 1)
@@ -145,9 +152,11 @@ def main():
         pmc = os.path.join(ROOT, "profiles", f"r01_{args.precision}_conv_pmc.json")
         if os.path.exists(pmc):
             traffic = json.load(open(pmc))["all_conv_igemm"]["traffic_bytes_per_launch"]
-        roofline = dict(bound="mfma", achieved=achieved, peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
-                        frac=achieved / PEAK_F32_MFMA_TFLOPS, traffic=traffic,
-                        kernel="m3d::conv_igemm_f32_kernel<*> (all tile shapes)", launches_per_step=nl // min(args.steps, 5),
+        peak = PEAK[args.precision]
+        kname = "m3d::conv_igemm_f32_kernel<*>" if args.precision == "f32" else "m3d::conv_igemm_dma_kernel<*>"
+        roofline = dict(bound="mfma", achieved=achieved, peak=peak, unit="TFLOP/s",
+                        frac=achieved / peak, traffic=traffic, frac_of_f32_matrix_peak=achieved / PEAK_F32_MFMA_TFLOPS,
+                        kernel=kname + " (all tile shapes)", launches_per_step=nl // min(args.steps, 5),
                         flop_per_launch=flops / nl, avg_launch_us=secs / nl * 1e6,
                         conv_share_of_step=secs / min(args.steps, 5) / (elapsed / args.steps))
         cb = None
@@ -161,7 +170,7 @@ def main():
         st = eng.last_stats
         line = dict(metric="voxels/sec SpUNet fwd", value=nvox_all / elapsed, unit="voxels/s", n_gpus=world,
                     steps=args.steps, warmup=args.warmup, ms_per_step=elapsed / args.steps * 1e3,
-                    higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
+                    higher_is_better=True, scaling="weak", vs_baseline=None, dtype=DTYPE[args.precision], data="synthetic",
                     config=dict(workload="configs[1]: synthetic ScanNet-scale scene @2 cm, spunet34c+ppt forward "
                                          "fp32 + 768-d CLIP-text argmax (C=200), voxelize+kernel maps included",
                                 scenes_per_gpu=args.scenes_per_rank, voxels_per_scene=st.get("n_voxels", [0])[0],

@@ -109,6 +109,67 @@ __device__ inline void conv_epilogue(const ConvArgs& a, const floatx16 (&acc)[NT
   }
 }
 
+// Epilogue through an LDS image of the output tile: the accumulators (with the per-channel affine
+// applied) are written to S[BM][BN] f32, then every thread finishes 8 consecutive channels of one row
+// (residual, ReLU) and stores them with 16/32-byte accesses: f32 row segment and/or the sf32 terms.
+template <int WM, int WN, int NT>
+__device__ inline void conv_epilogue_staged(const ConvArgs& a, const floatx16 (&acc)[NT], const int* orow_s,
+                                            float* S, int col_base, int wm, int wn, int lane, int tid) {
+  constexpr int BM = 32 * WM, BN = 32 * NT * WN, NTHR = 64 * WM * WN;
+  const int h = lane >> 5, cl = lane & 31;
+  if (blockIdx.x == 0 && blockIdx.y == 0) clear_zero_row(a);
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int lc = (wn * NT + nt) * 32 + cl;
+    const float sc = a.scale ? a.scale[col_base + lc] : 1.f;
+    const float sh = a.shift ? a.shift[col_base + lc] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int rl = (r & 3) + 8 * (r >> 2) + 4 * h;
+      S[(wm * 32 + rl) * BN + lc] = acc[nt][r] * sc + sh;
+    }
+  }
+  __syncthreads();
+  constexpr int CPR = BN / 4;  // 4-channel pieces per row: consecutive lanes store consecutive 16 B (f32) / 8 B (bf16)
+  for (int e = tid; e < BM * CPR; e += NTHR) {
+    const int r = e / CPR, c4 = e % CPR;
+    const int orow = orow_s[r];
+    if (orow < 0) continue;
+    const float4 v0 = *reinterpret_cast<const float4*>(S + r * BN + c4 * 4);
+    float v[4] = {v0.x, v0.y, v0.z, v0.w};
+    const int col = col_base + c4 * 4;
+    if (a.residual) {
+      const float4 q0 = *reinterpret_cast<const float4*>(a.residual + (int64_t)orow * a.cout + col);
+      v[0] += q0.x; v[1] += q0.y; v[2] += q0.z; v[3] += q0.w;
+    }
+    if (a.relu) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
+    }
+    if (a.out) {
+      float* o = a.out + (int64_t)orow * a.ldo + col;
+      if ((a.ldo & 3) == 0) {
+        *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = v[i];
+      }
+    }
+    if (a.out_split) {
+      char* base = a.out_split + (((int64_t)orow * (a.cout >> 5) + (col >> 5)) * a.terms) * 64 + (col & 31) * 2;
+      for (int t = 0; t < a.terms; ++t) {
+        bf16x4 q;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          q[i] = (__bf16)v[i];
+          v[i] -= (float)q[i];
+        }
+        *reinterpret_cast<bf16x4*>(base + t * 64) = q;
+      }
+    }
+  }
+}
+
 // Workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8 share an L2).  Map block ids so
 // that each XCD walks a contiguous range of the (spatially sorted) tile schedule: neighbouring tiles
 // gather overlapping input rows, which then hit in that XCD's L2.  Bijective for any tile count.
@@ -665,7 +726,12 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvArgs& a) {
     if (s < nstage) M3D_DMA_STEP(s, 0)
 #undef M3D_DMA_STEP
   }
-  conv_epilogue<NT>(a, acc, orow_s, tile_base, col_base, wm, wn, lane);
+  if (a.slab || (a.dbg & 32)) {
+    conv_epilogue<NT>(a, acc, orow_s, tile_base, col_base, wm, wn, lane);
+  } else {
+    __syncthreads();  // every wave is done with the staging buffers; reuse them for the output tile
+    conv_epilogue_staged<WM, WN, NT>(a, acc, orow_s, reinterpret_cast<float*>(ldsb), col_base, wm, wn, lane, tid);
+  }
 }
 
 template <int WM, int WN, int NT, int T>
@@ -799,6 +865,7 @@ static int launch_split(const ConvArgs& a, int nz, hipStream_t stream) {
 template <int WM, int WN, int NT, int T>
 static int launch_dma(const ConvArgs& a, int nz, hipStream_t stream) {
   constexpr int BM = 32 * WM, BN = 32 * NT * WN, NTHR = 64 * WM * WN;
+  static_assert((size_t)BM * BN * sizeof(float) <= (size_t)2 * (BM + BN) * DmaGeom<T>::ROWB, "output tile must fit in the staging buffers");
   const size_t lds = (size_t)2 * (BM + BN) * DmaGeom<T>::ROWB + (size_t)(a.kvol + 1) * BM * sizeof(int);
   static size_t attr_lds = 0;
   if (lds > attr_lds) {

@@ -65,7 +65,8 @@ class SpUNetEngine:
         self.cfg = cfg
         self.precision = precision
         self._terms = {"f32": 0, "bf16x3": 2, "bf16x6": 3}[precision]
-        self.head_precision = "f32"  # the logits GEMM reads the f32 features the caller also receives
+        # with a split precision `final` also writes an sf32 copy of the features for the logits GEMM
+        self.head_precision = precision
         self.device = torch.device(device)
         self.channels, self.layers = tuple(cfg["channels"]), tuple(cfg["layers"])
         self.num_stages = len(self.layers) // 2
@@ -203,16 +204,19 @@ class SpUNetEngine:
                 keep[f"dec.{s}"] = x[0]
         return x
 
-    def forward_features(self, coord, feat, offset, grid_size, keep=None):
+    def forward_features(self, coord, feat, offset, grid_size, keep=None, want_split=False):
         """Whole path up to the per-voxel open-vocabulary features.  Returns (features [N0, D], vox dict)."""
         vox = ops.voxelize(coord, feat, offset, grid_size, pad=128)
         levels = self.build_levels(vox["voxel_coords"], vox["spatial_shape"], vox["batch_size"])
         x = self.backbone(vox["voxel_feats"], levels, keep)
-        out = self._conv(self.final, x, None, levels[0].n, need_f32=True, need_sf=False)[0]
+        out_pair = self._conv(self.final, x, None, levels[0].n, need_f32=True, need_sf=want_split)
+        out = out_pair[0]
         if keep is not None:
             keep["final"] = out
             keep["levels"] = levels
         self.last_stats = dict(n_points=int(coord.shape[0]), n_voxels=[lv.n for lv in levels])
+        if want_split:
+            return out_pair, vox
         return out, vox
 
     @torch.no_grad()
@@ -229,8 +233,10 @@ class SpUNetEngine:
             logits = ops.conv_fwd(src, t.w, None, levels[0].n, shift=t.shift, flop_cout=self.n_classes)
             self.last_stats = dict(n_points=int(coord.shape[0]), n_voxels=[lv.n for lv in levels])
         else:
-            feats, vox = self.forward_features(coord, feat, offset, grid_size)
-            logits = ops.conv_fwd(feats, self.text.w, None, feats.shape[0], flop_cout=self.n_classes)
+            pair, vox = self.forward_features(coord, feat, offset, grid_size, want_split=self._terms != 0)
+            feats = pair[0] if self._terms else pair
+            src = pair[1] if self._terms else feats
+            logits = ops.conv_fwd(src, self.text.w, None, feats.shape[0], flop_cout=self.n_classes)
         vlabel = ops.argmax_rows(logits, self.n_classes)
         plabel = ops.gather_labels(vlabel, vox["v2p_map"])
         out = dict(pred=plabel, voxel_pred=vlabel, v2p_map=vox["v2p_map"], n_voxels=vox["n_voxels"])
