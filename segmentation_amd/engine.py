@@ -52,7 +52,8 @@ class _Conv:
 
 class _Level:
     """Kernel maps of one resolution level."""
-    __slots__ = ("indices", "shape", "n", "subm", "down", "up", "pair_subm", "pair_fwd", "pair_bwd")
+    __slots__ = ("indices", "shape", "n", "subm", "down", "up", "pair_subm", "pair_fwd", "pair_bwd",
+                 "next_indices", "next_shape", "n_next")
 
 
 class SpUNetEngine:
@@ -126,25 +127,33 @@ class SpUNetEngine:
         self.text_folded = _Conv(ops.pack_weight(wfold, self.precision), None, bfold.contiguous())
 
     # ------------------------------------------------------------------ kernel maps
+    def _build_level(self, l, idx, shape, batch_size):
+        lv = _Level()
+        lv.indices, lv.shape, lv.n = idx, shape, idx.shape[0]
+        lv.pair_subm = ops.subm_rulebook(idx, shape)
+        lv.subm = ops.build_schedule(lv.pair_subm, lv.n, idx, 1 if l == 0 else 0, shape, batch_size)
+        lv.down = lv.up = lv.pair_fwd = lv.pair_bwd = None
+        lv.next_indices = lv.next_shape = None
+        lv.n_next = 0
+        if l < self.num_stages:
+            oi, oshape, pf, pb = ops.strided_rulebook(idx, shape, batch_size)
+            lv.pair_fwd, lv.pair_bwd = pf, pb
+            lv.down = ops.build_schedule(pf, oi.shape[0], None, 0)
+            lv.up = ops.build_schedule(pb, lv.n, None, 2, base_order=lv.subm.out_row)
+            lv.next_indices, lv.next_shape, lv.n_next = oi, oshape, oi.shape[0]
+        return lv
+
     def build_levels(self, voxel_coords, spatial_shape, batch_size=1):
         """Kernel maps + tile schedules of every resolution level.  Level 0 rows arrive in hash order and
         are walked in Morton order; deeper levels are already in row-major spatial order."""
         levels = []
         idx, shape = voxel_coords, list(spatial_shape)
         for l in range(self.num_stages + 1):
-            lv = _Level()
-            lv.indices, lv.shape, lv.n = idx, shape, idx.shape[0]
-            lv.pair_subm = ops.subm_rulebook(idx, shape)
-            lv.subm = ops.build_schedule(lv.pair_subm, lv.n, idx, 1 if l == 0 else 0, shape, batch_size)
-            lv.down = lv.up = lv.pair_fwd = lv.pair_bwd = None
+            lv = self._build_level(l, idx, shape, batch_size)
             levels.append(lv)
-            if l < self.num_stages:
-                oi, oshape, pf, pb = ops.strided_rulebook(idx, shape, batch_size)
-                lv.pair_fwd, lv.pair_bwd = pf, pb
-                lv.down = ops.build_schedule(pf, oi.shape[0], None, 0)
-                lv.up = ops.build_schedule(pb, lv.n, None, 2, base_order=lv.subm.out_row)
-                idx, shape = oi, oshape
+            idx, shape = lv.next_indices, lv.next_shape
         return levels
+
 
     # ------------------------------------------------------------------ network
     # Activations travel as (f32 tensor or None, SplitTensor or None).  With precision "f32" only the f32
@@ -184,7 +193,7 @@ class SpUNetEngine:
             keep["conv_input"] = x[0]
         skips = [x]
         for s in range(ns):
-            x = self._conv(self.down[s], x, levels[s].down, levels[s + 1].n, relu=True, need_f32=True)
+            x = self._conv(self.down[s], x, levels[s].down, levels[s].n_next, relu=True, need_f32=True)
             if keep is not None:
                 keep[f"down.{s}"] = x[0]
             for blk in self.enc[s]:
@@ -204,17 +213,22 @@ class SpUNetEngine:
                 keep[f"dec.{s}"] = x[0]
         return x
 
+    def _voxelize_and_maps(self, coord, feat, offset, grid_size):
+        # (Building the maps on a side stream overlapped with the encoder was tried and measured slower:
+        #  the map kernels are latency-bound on their host read-backs, not on GPU time.)
+        vox = ops.voxelize(coord, feat, offset, grid_size, pad=128)
+        return vox, self.build_levels(vox["voxel_coords"], vox["spatial_shape"], vox["batch_size"])
+
     def forward_features(self, coord, feat, offset, grid_size, keep=None, want_split=False):
         """Whole path up to the per-voxel open-vocabulary features.  Returns (features [N0, D], vox dict)."""
-        vox = ops.voxelize(coord, feat, offset, grid_size, pad=128)
-        levels = self.build_levels(vox["voxel_coords"], vox["spatial_shape"], vox["batch_size"])
+        vox, levels = self._voxelize_and_maps(coord, feat, offset, grid_size)
         x = self.backbone(vox["voxel_feats"], levels, keep)
         out_pair = self._conv(self.final, x, None, levels[0].n, need_f32=True, need_sf=want_split)
         out = out_pair[0]
         if keep is not None:
             keep["final"] = out
-            keep["levels"] = levels
-        self.last_stats = dict(n_points=int(coord.shape[0]), n_voxels=[lv.n for lv in levels])
+            keep["levels"] = [levels[l] for l in range(len(levels))]
+        self.last_stats = dict(n_points=int(coord.shape[0]), n_voxels=[levels[l].n for l in range(len(levels))])
         if want_split:
             return out_pair, vox
         return out, vox
@@ -225,13 +239,12 @@ class SpUNetEngine:
         if self.text is None:
             raise RuntimeError("call set_text_embeddings() first")
         if fold_head:
-            vox = ops.voxelize(coord, feat, offset, grid_size, pad=128)
-            levels = self.build_levels(vox["voxel_coords"], vox["spatial_shape"], vox["batch_size"])
+            vox, levels = self._voxelize_and_maps(coord, feat, offset, grid_size)
             x = self.backbone(vox["voxel_feats"], levels)
             t = self.text_folded
             src = x[1] if self._terms else x[0]
             logits = ops.conv_fwd(src, t.w, None, levels[0].n, shift=t.shift, flop_cout=self.n_classes)
-            self.last_stats = dict(n_points=int(coord.shape[0]), n_voxels=[lv.n for lv in levels])
+            self.last_stats = dict(n_points=int(coord.shape[0]), n_voxels=[levels[l].n for l in range(len(levels))])
         else:
             pair, vox = self.forward_features(coord, feat, offset, grid_size, want_split=self._terms != 0)
             feats = pair[0] if self._terms else pair
