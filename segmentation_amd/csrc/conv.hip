@@ -792,6 +792,81 @@ __global__ __launch_bounds__(256) void conv_reduce_kernel(ConvArgs a, int nz) {
   if (a.out_split) store_split(a.out_split, orow, col, a.cout, a.terms, v);
 }
 
+// Few input channels (the 3-channel stem): one thread per output row computes CO output channels; the
+// weights sit in LDS as [k][cin][CO] and are read as wave-wide broadcasts, the kernel map is read once per
+// (row, offset) instead of once per output channel.
+template <int CO>
+__global__ __launch_bounds__(256) void conv_rowwise_f32_kernel(ConvArgs a) {
+  extern __shared__ __align__(16) float wsm[];  // [kvol][cin][CO]
+  const int cin = a.c0;
+  const int co_base = blockIdx.y * CO;
+  for (int i = threadIdx.x; i < a.kvol * cin * CO; i += blockDim.x) {
+    const int o = i % CO, c = (i / CO) % cin, k = i / (CO * cin);
+    wsm[i] = a.weight[((int64_t)k * a.cout + co_base + o) * cin + c];
+  }
+  if (blockIdx.x == 0 && blockIdx.y == 0) clear_zero_row(a);
+  __syncthreads();
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= a.npad) return;
+  const int orow = a.out_row ? a.out_row[t] : (t < a.n ? (int)t : -1);
+  if (orow < 0) return;
+  float acc[CO];
+#pragma unroll
+  for (int o = 0; o < CO; ++o) acc[o] = 0.f;
+  for (int k = 0; k < a.kvol; ++k) {
+    const int id = a.nbr ? a.nbr[(int64_t)k * a.npad + t] : (int)t;
+    if (id < 0) continue;
+    const float* x = a.in0 + (int64_t)id * cin;
+    for (int c = 0; c < cin; ++c) {
+      const float xv = x[c];
+      const float4* w4 = reinterpret_cast<const float4*>(wsm + (k * cin + c) * CO);
+#pragma unroll
+      for (int o4 = 0; o4 < CO / 4; ++o4) {
+        const float4 w = w4[o4];
+        acc[o4 * 4 + 0] = fmaf(xv, w.x, acc[o4 * 4 + 0]);
+        acc[o4 * 4 + 1] = fmaf(xv, w.y, acc[o4 * 4 + 1]);
+        acc[o4 * 4 + 2] = fmaf(xv, w.z, acc[o4 * 4 + 2]);
+        acc[o4 * 4 + 3] = fmaf(xv, w.w, acc[o4 * 4 + 3]);
+      }
+    }
+  }
+  float v[CO];
+#pragma unroll
+  for (int o = 0; o < CO; ++o) {
+    const int col = co_base + o;
+    float y = acc[o] * (a.scale ? a.scale[col] : 1.f) + (a.shift ? a.shift[col] : 0.f);
+    if (a.residual) y += a.residual[(int64_t)orow * a.cout + col];
+    if (a.relu) y = fmaxf(y, 0.f);
+    v[o] = y;
+  }
+  if (a.out) {
+    float* o = a.out + (int64_t)orow * a.ldo + co_base;
+    if ((a.ldo & 3) == 0) {
+#pragma unroll
+      for (int o4 = 0; o4 < CO / 4; ++o4)
+        reinterpret_cast<float4*>(o)[o4] = make_float4(v[o4 * 4], v[o4 * 4 + 1], v[o4 * 4 + 2], v[o4 * 4 + 3]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < CO; ++i) o[i] = v[i];
+    }
+  }
+  if (a.out_split) {  // CO == 32: exactly one channel group
+    char* base = a.out_split + (((int64_t)orow * (a.cout >> 5) + (co_base >> 5)) * a.terms) * 64;
+    for (int tt = 0; tt < a.terms; ++tt) {
+#pragma unroll
+      for (int o8 = 0; o8 < CO / 8; ++o8) {
+        bf16x8 q;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          q[i] = (__bf16)v[o8 * 8 + i];
+          v[o8 * 8 + i] -= (float)q[i];
+        }
+        *reinterpret_cast<bf16x8*>(base + tt * 64 + o8 * 16) = q;
+      }
+    }
+  }
+}
+
 // Any channel counts (used for the 3-channel stem and for shapes that are not multiples of 32):
 // one thread per (schedule row, output channel), plain f32 FMA chain over (k, cin).
 __global__ __launch_bounds__(256) void conv_direct_f32_kernel(ConvArgs a) {
@@ -935,6 +1010,13 @@ static int run_conv(ConvArgs& a, int mode, bool mfma_ok, void* d_ws, size_t ws_b
     if (mode >= 3) {
       set_error("%s: channel counts must be multiples of 32", who);
       return M3D_EINVAL;
+    }
+    if (a.c1 == 0 && a.c0 <= 8 && a.cout % 32 == 0) {  // the stem: rows x 32-channel groups
+      const size_t lds = (size_t)a.kvol * a.c0 * 32 * sizeof(float);
+      hipLaunchKernelGGL(conv_rowwise_f32_kernel<32>, dim3((unsigned)cdiv(a.npad, 256), (unsigned)(a.cout / 32)),
+                         dim3(256), lds, stream, a);
+      M3D_LAUNCH_CHECK();
+      return M3D_OK;
     }
     const int64_t total = a.npad * a.cout;
     const size_t wbytes = (size_t)a.kvol * a.cout * (a.c0 + a.c1) * sizeof(float);
