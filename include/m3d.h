@@ -101,11 +101,15 @@ int m3d_strided_rulebook(const int32_t* d_indices, int64_t n, const int64_t spat
  * Tile schedule of a kernel map: the order in which the convolution kernel walks output rows.
  * Has no counterpart in the reference (spconv keeps this inside its implicit-GEMM planner).
  *   d_pair [k,ld] i32  canonical kernel map (ld = column stride, n valid columns)
- *   d_indices [n,4]    coordinates of the OUTPUT rows (mode 1 only, else may be NULL)
- *   spatial_shape, batch_size: bounds of d_indices (mode 1; spatial_shape may be NULL)
+ *   d_indices [n,4]    coordinates of the OUTPUT rows (modes 1 and 3, else may be NULL)
+ *   spatial_shape, batch_size: bounds of d_indices (modes 1 and 3; spatial_shape may be NULL)
  *   d_base_order [n]   optional starting permutation of the rows (NULL = identity)
  *   mode 0: the base order as is; 1: Morton order of d_indices; 2: rows grouped by their first
- *           active kernel offset (inverse conv), base order kept inside a group
+ *           active kernel offset (inverse conv), base order kept inside a group; 3 (k = 27 only):
+ *           rows grouped by coarse spatial cell (2^s voxels per side, cells in Morton order; s is
+ *           passed as mode = 3 | s << 8, s = 0 means 6, s = 15 one cell) and, inside a cell, by
+ *           which corner/edge offsets of the 3x3x3 stencil they have, so that the rows of a tile
+ *           miss the same offsets and the tile skips them
  * outputs, npad = m3d_schedule_npad(n):
  *   d_nbr      [k,npad] i32  nbr[k][t] = pair[k][row(t)], -1 in the padding
  *   d_out_row  [npad]   i32  row(t), -1 in the padding

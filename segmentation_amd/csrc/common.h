@@ -86,9 +86,11 @@ size_t unique_ws_bytes(int64_t nmax);
 // Stable LSD radix sort of (key, value) pairs, ascending by key bits [0, nbits).
 // The element count is read from *d_count on the device (<= nmax).  On return the sorted
 // pairs are in (d_keys, d_vals); (d_keys_alt, d_vals_alt) are clobbered.
+// With result_in_alt != nullptr the pass count is not rounded up to an even number: *result_in_alt says
+// whether the sorted pairs ended in the alt buffers (odd pass count) or in (d_keys, d_vals).
 int sort_pairs(uint64_t* d_keys, uint32_t* d_vals, uint64_t* d_keys_alt, uint32_t* d_vals_alt,
                const int* d_count, int64_t nmax, int nbits, void* d_ws, size_t ws_bytes,
-               hipStream_t stream);
+               hipStream_t stream, bool* result_in_alt = nullptr);
 
 // np.unique(keys, return_inverse=True) plus one representative input index per unique key.
 //   d_keys [n] input; outputs: d_ukeys [n] ascending unique keys, d_rep [n] an input index

@@ -634,11 +634,12 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvArgs& a) {
     const int zero = (int)(first ? a.zero0 : a.zero1);
 #pragma unroll
     for (int v = 0; v < A_V; ++v) {
-      const uint32_t row = (uint32_t)(a_id[v] < 0 ? zero : a_id[v]);
+      const uint32_t row = (uint32_t)((a_id[v] < 0 || (a.dbg & 2)) ? zero : a_id[v]);
       const char* g = src + ((uint64_t)row * rowb + a_p[v]);
-      if (a_on[v]) __builtin_amdgcn_global_load_lds(g, (lds_ptr_t)(buf + (v * NTHR + wave * 64) * 16), 16, 0, 0);
+      if (a_on[v] && (!(a.dbg & 8) || a_id[v] >= 0 || lane < 8))
+        __builtin_amdgcn_global_load_lds(g, (lds_ptr_t)(buf + (v * NTHR + wave * 64) * 16), 16, 0, 0);
     }
-    const char* wsrc = wsplit + ((uint64_t)ik * wk_stride + (uint32_t)icc * GRPB);
+    const char* wsrc = wsplit + ((a.dbg & 4) ? 0 : ((uint64_t)ik * wk_stride + (uint32_t)icc * GRPB));
 #pragma unroll
     for (int v = 0; v < W_V; ++v)
       if (w_on[v])
@@ -707,7 +708,7 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvArgs& a) {
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                     \
     __builtin_amdgcn_s_barrier();                                                             \
     asm volatile("" ::: "memory");                                                            \
-    if ((wmask >> ck) & 1u) compute(BI);                                                      \
+    if (((wmask >> ck) & 1u) && !(a.dbg & 1)) compute(BI);                                    \
     if (++ccc == nchunk) {                                                                    \
       ccc = 0;                                                                                \
       crem &= crem - 1;                                                                       \

@@ -140,7 +140,8 @@ size_t sort_pairs_ws_bytes(int64_t nmax) {
 
 int sort_pairs(uint64_t* d_keys, uint32_t* d_vals, uint64_t* d_keys_alt, uint32_t* d_vals_alt,
                const int* d_count, int64_t nmax, int nbits, void* d_ws, size_t ws_bytes,
-               hipStream_t stream) {
+               hipStream_t stream, bool* result_in_alt) {
+  if (result_in_alt) *result_in_alt = false;
   if (nmax <= 0) return M3D_OK;
   const int nchunks = (int)cdiv(nmax, kWaveItems);
   if (ws_bytes < sort_pairs_ws_bytes(nmax) || d_ws == nullptr) {
@@ -151,9 +152,10 @@ int sort_pairs(uint64_t* d_keys, uint32_t* d_vals, uint64_t* d_keys_alt, uint32_
   uint32_t* totals = reinterpret_cast<uint32_t*>(static_cast<char*>(d_ws) +
                                                  align_up((size_t)nchunks * 256 * sizeof(uint32_t)));
   int passes = (nbits + 7) / 8;
-  if (passes < 2) passes = 2;
-  if (passes & 1) ++passes;  // an even number of passes leaves the result in (d_keys, d_vals)
+  if (passes < 1) passes = 1;
   if (passes > 8) passes = 8;
+  if (result_in_alt) *result_in_alt = passes & 1;
+  else if (passes & 1) ++passes;  // an even number of passes leaves the result in (d_keys, d_vals)
   const int nblocks = (int)cdiv(nchunks, kSortBlock / 64);
   uint64_t* ki = d_keys;
   uint32_t* vi = d_vals;

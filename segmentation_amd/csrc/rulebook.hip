@@ -145,6 +145,32 @@ __global__ void sched_key_kernel(const int32_t* __restrict__ pair, int kvol, int
   vals[t] = (uint32_t)row;
 }
 
+// mode 3: key = batch | Morton of the coarse cell (x, y, z) >> cs | neighbour pattern.  Inside a cell of
+// 2^cs voxels per side rows are regrouped by their neighbour pattern, so that the rows of one tile tend
+// to miss the same kernel offsets and the tile can skip them.  The pattern is compared with the rarest
+// offsets first (corners, then edges of the 3x3x3 stencil); faces and centre are nearly always present.
+// The sort is stable: rows keep the base order inside a (cell, pattern) group.
+__global__ void sched_pattern_key_kernel(const int32_t* __restrict__ pair, int64_t ld, int64_t n,
+                                         const int4* __restrict__ idx, int cs, int cb,
+                                         uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+  const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= n) return;
+  uint32_t corner = 0, edge = 0;  // 8 + 12 bits
+  for (int k = 0; k < 27; ++k) {
+    const int nz = (k / 9 != 1) + ((k / 3) % 3 != 1) + (k % 3 != 1);
+    if (nz < 2) continue;
+    const uint32_t bit = pair[(int64_t)k * ld + row] >= 0 ? 1u : 0u;
+    if (nz == 3) corner = (corner << 1) | bit;
+    else edge = (edge << 1) | bit;
+  }
+  const int4 c = idx[row];
+  const uint64_t m = (spread3((uint64_t)(c.y >> cs)) << 2) | (spread3((uint64_t)(c.z >> cs)) << 1) |
+                     spread3((uint64_t)(c.w >> cs));
+  const uint64_t cell = ((uint64_t)c.x << (3 * cb)) | (m & ((1ull << (3 * cb)) - 1));
+  keys[row] = (cell << 20) | (corner << 12) | edge;
+  vals[row] = (uint32_t)row;
+}
+
 __global__ __launch_bounds__(256) void sched_gather_kernel(const int32_t* __restrict__ pair, int64_t ld,
                                                            int64_t n, int64_t npad,
                                                            const uint32_t* __restrict__ order,
@@ -296,7 +322,10 @@ extern "C" int m3d_build_schedule(const int32_t* d_pair, int k, int64_t ld, int6
   M3D_CHECK_ARG(n > 0 && n < (int64_t)INT_MAX, "m3d_build_schedule: n out of range");
   M3D_CHECK_ARG(k >= 1 && k <= 27 && ld >= n, "m3d_build_schedule: k=%d ld=%lld", k, (long long)ld);
   M3D_CHECK_ARG(d_pair && d_nbr && d_out_row && d_tile_mask, "m3d_build_schedule: null pointer");
-  M3D_CHECK_ARG(mode >= 0 && mode <= 2, "m3d_build_schedule: unknown mode %d", mode);
+  const int cell_shift = (mode >> 8) & 0xFF;  // mode 3 only: log2 of the cell side, 0 = default
+  mode &= 0xFF;
+  M3D_CHECK_ARG(mode >= 0 && mode <= 3, "m3d_build_schedule: unknown mode %d", mode);
+  M3D_CHECK_ARG(mode != 3 || k == 27, "m3d_build_schedule: mode 3 needs a 3x3x3 kernel map (k=%d)", k);
   const int64_t npad = m3d_schedule_npad(n);
   const int bs = 256;
   const uint32_t* order = nullptr;
@@ -314,8 +343,8 @@ extern "C" int m3d_build_schedule(const int32_t* d_pair, int k, int64_t ld, int6
       return M3D_ENOSPC;
     }
     int mb = 16, nbits = 4;
-    if (mode == 1) {
-      M3D_CHECK_ARG(d_indices != nullptr, "m3d_build_schedule: mode 1 needs the output coordinates");
+    if (mode == 1 || mode == 3) {
+      M3D_CHECK_ARG(d_indices != nullptr, "m3d_build_schedule: modes 1 and 3 need the output coordinates");
       if (spatial_shape) {
         int64_t mx = spatial_shape[0];
         if (spatial_shape[1] > mx) mx = spatial_shape[1];
@@ -326,12 +355,22 @@ extern "C" int m3d_build_schedule(const int32_t* d_pair, int k, int64_t ld, int6
       nbits = 3 * mb + bits_for((uint64_t)(batch_size > 1 ? batch_size - 1 : 1));
     }
     hipLaunchKernelGGL(set_int_kernel, dim3(1), dim3(64), 0, stream, count, (int)n);
-    hipLaunchKernelGGL(sched_key_kernel, dim3((unsigned)cdiv(n, bs)), dim3(bs), 0, stream, d_pair, k, ld,
-                       n, reinterpret_cast<const int4*>(d_indices), mode, mb, d_base_order, keys, vals);
+    if (mode == 3) {
+      const int cs = cell_shift ? (cell_shift > 15 ? 15 : cell_shift) : 6;
+      const int cb = mb > cs ? mb - cs : 0;  // bits per axis of the cell coordinate
+      nbits = 20 + 3 * cb + bits_for((uint64_t)(batch_size > 1 ? batch_size - 1 : 1));
+      M3D_CHECK_ARG(d_base_order == nullptr, "m3d_build_schedule: mode 3 takes no base order");
+      hipLaunchKernelGGL(sched_pattern_key_kernel, dim3((unsigned)cdiv(n, bs)), dim3(bs), 0, stream, d_pair, ld, n,
+                         reinterpret_cast<const int4*>(d_indices), cs, cb, keys, vals);
+    } else {
+      hipLaunchKernelGGL(sched_key_kernel, dim3((unsigned)cdiv(n, bs)), dim3(bs), 0, stream, d_pair, k, ld,
+                         n, reinterpret_cast<const int4*>(d_indices), mode, mb, d_base_order, keys, vals);
+    }
     M3D_LAUNCH_CHECK();
-    int rc = sort_pairs(keys, vals, kalt, valt, count, n, nbits, sws, sb, stream);
+    bool in_alt = false;
+    int rc = sort_pairs(keys, vals, kalt, valt, count, n, nbits, sws, sb, stream, &in_alt);
     if (rc != M3D_OK) return rc;
-    order = vals;
+    order = in_alt ? valt : vals;
   }
   if (mode == 0 && d_base_order) order = reinterpret_cast<const uint32_t*>(d_base_order);
   hipLaunchKernelGGL(sched_gather_kernel, dim3((unsigned)cdiv(npad, bs), k), dim3(bs), 0, stream, d_pair,

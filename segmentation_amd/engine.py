@@ -17,6 +17,7 @@ spconv_unet_v1m3_pdnorm.py:380-414 in eval mode.  What is restructured for MI355
 """
 from typing import Dict, Optional, Sequence
 
+import os
 import torch
 
 from . import ops, sparse
@@ -65,6 +66,9 @@ class SpUNetEngine:
         sd = {k: v.detach().to("cpu") for k, v in sd.items()}
         self.cfg = cfg
         self.precision = precision
+        # schedule mode of the submanifold maps per level (the last entry repeats): pattern-grouped cells of
+        # 64 / 32 voxels per side at the two large levels, one cell where the level fits in L2, voxel order below
+        self.sched_modes = [int(m) for m in os.environ.get("M3D_SCHED_MODES", "1539,1283,3843,0").split(",")]
         self._terms = {"f32": 0, "bf16x3": 2, "bf16x6": 3}[precision]
         # with a split precision `final` also writes an sf32 copy of the features for the logits GEMM
         self.head_precision = precision
@@ -131,7 +135,8 @@ class SpUNetEngine:
         lv = _Level()
         lv.indices, lv.shape, lv.n = idx, shape, idx.shape[0]
         lv.pair_subm = ops.subm_rulebook(idx, shape)
-        lv.subm = ops.build_schedule(lv.pair_subm, lv.n, idx, 1 if l == 0 else 0, shape, batch_size)
+        lv.subm = ops.build_schedule(lv.pair_subm, lv.n, idx, self.sched_modes[min(l, len(self.sched_modes) - 1)], shape,
+                                     batch_size)
         lv.down = lv.up = lv.pair_fwd = lv.pair_bwd = None
         lv.next_indices = lv.next_shape = None
         lv.n_next = 0
@@ -219,11 +224,12 @@ class SpUNetEngine:
         vox = ops.voxelize(coord, feat, offset, grid_size, pad=128)
         return vox, self.build_levels(vox["voxel_coords"], vox["spatial_shape"], vox["batch_size"])
 
-    def forward_features(self, coord, feat, offset, grid_size, keep=None, want_split=False):
-        """Whole path up to the per-voxel open-vocabulary features.  Returns (features [N0, D], vox dict)."""
+    def forward_features(self, coord, feat, offset, grid_size, keep=None, want_split=False, want_f32=True):
+        """Whole path up to the per-voxel open-vocabulary features.  Returns (features [N0, D], vox dict); with
+        want_split the first member is the pair (f32 features or None, split features)."""
         vox, levels = self._voxelize_and_maps(coord, feat, offset, grid_size)
         x = self.backbone(vox["voxel_feats"], levels, keep)
-        out_pair = self._conv(self.final, x, None, levels[0].n, need_f32=True, need_sf=want_split)
+        out_pair = self._conv(self.final, x, None, levels[0].n, need_f32=want_f32 or not want_split, need_sf=want_split)
         out = out_pair[0]
         if keep is not None:
             keep["final"] = out
@@ -246,10 +252,11 @@ class SpUNetEngine:
             logits = ops.conv_fwd(src, t.w, None, levels[0].n, shift=t.shift, flop_cout=self.n_classes)
             self.last_stats = dict(n_points=int(coord.shape[0]), n_voxels=[levels[l].n for l in range(len(levels))])
         else:
-            pair, vox = self.forward_features(coord, feat, offset, grid_size, want_split=self._terms != 0)
-            feats = pair[0] if self._terms else pair
-            src = pair[1] if self._terms else feats
-            logits = ops.conv_fwd(src, self.text.w, None, feats.shape[0], flop_cout=self.n_classes)
+            # the head consumes the split features directly; the f32 copy is only written when asked for
+            pair, vox = self.forward_features(coord, feat, offset, grid_size, want_split=self._terms != 0,
+                                              want_f32=False)
+            src = pair[1] if self._terms else pair
+            logits = ops.conv_fwd(src, self.text.w, None, self.last_stats["n_voxels"][0], flop_cout=self.n_classes)
         vlabel = ops.argmax_rows(logits, self.n_classes)
         plabel = ops.gather_labels(vlabel, vox["v2p_map"])
         out = dict(pred=plabel, voxel_pred=vlabel, v2p_map=vox["v2p_map"], n_voxels=vox["n_voxels"])

@@ -69,9 +69,9 @@ class ImplicitGemmIndiceData:
     def sched_fwd(self):
         if self._sched_fwd is None:
             n_out = self.out_indices.shape[0]
-            # submanifold maps walk the voxels in Morton order; strided outputs are already in
-            # row-major spatial order
-            mode = 1 if self.is_subm else 0
+            # submanifold maps walk the voxels cell by cell, grouped by neighbour pattern (3x3x3) or in
+            # Morton order (other kernel sizes); strided outputs are already in row-major spatial order
+            mode = (3 if self.pair_fwd.shape[0] == 27 else 1) if self.is_subm else 0
             self._sched_fwd = ops.build_schedule(self.pair_fwd, n_out, self.out_indices if mode else None, mode,
                                                  self.out_spatial_shape, self.batch_size)
         return self._sched_fwd

@@ -58,7 +58,7 @@ def test_strided_rulebook_drops_rows_outside_the_output_shape(device):
     assert np.array_equal(pb.cpu().numpy(), rpb)
 
 
-@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
 def test_schedule_is_a_permutation_of_the_kernel_map(device, mode):
     sp = _voxels(3, 9000)
     idx = torch.from_numpy(sp["voxel_coords"]).to(device)
@@ -94,3 +94,14 @@ def test_schedule_is_a_permutation_of_the_kernel_map(device, mode):
         from tools.mask_study_helpers import morton_key
         mk = morton_key(sp["voxel_coords"][orow[:n]])
         assert (np.diff(mk.astype(np.float64)) >= 0).all()
+    if mode == 3:  # coarse cells (64 voxels per side) in Morton order, inside a cell by corner/edge pattern
+        from tools.mask_study_helpers import morton_key
+        nz = lambda k: (k // 9 != 1) + ((k // 3) % 3 != 1) + (k % 3 != 1)
+        order_bits = [k for k in range(27) if nz(k) == 3] + [k for k in range(27) if nz(k) == 2]
+        pat = np.zeros(n, dtype=np.uint64)
+        for k in order_bits:
+            pat = (pat << np.uint64(1)) | (p[k] >= 0).astype(np.uint64)
+        vc = sp["voxel_coords"].copy()
+        vc[:, 1:] >>= 6
+        key = (morton_key(vc).astype(np.uint64) << np.uint64(20)) | pat
+        assert np.array_equal(orow[:n], np.argsort(key, kind="stable"))

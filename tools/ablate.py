@@ -24,8 +24,12 @@ def t(fn, reps=5):
     for _ in range(reps): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps * 1e3
-for dbg, name in [(0, "full"), (1, "no MFMA"), (2, "no A loads"), (4, "no W loads"), (6, "no A,W loads"),
-                  (1 | 2, "no MFMA, no A"), (1 | 4, "no MFMA, no W"), (1 | 2 | 4, "skeleton")]:
+CASES = [(0, "full"), (1, "no MFMA"), (2, "no A loads"), (4, "no W loads"), (6, "no A,W loads"),
+         (1 | 2, "no MFMA, no A"), (1 | 4, "no MFMA, no W"), (1 | 2 | 4, "skeleton")]
+if len(sys.argv) > 2 and sys.argv[2] == "dma":
+    CASES = [(0, "full"), (1, "no compute"), (2, "A from zero row"), (4, "W from one tile"), (6, "A zero, W one"),
+             (8, "A lanes masked"), (8 | 4, "A masked, W one"), (1 | 2 | 4, "no compute, A zero, W one"), (1 | 8, "no compute, A masked")]
+for dbg, name in CASES:
     os.environ["M3D_DBG"] = str(dbg)
     a = t(lambda: ops.conv_fwd(x, w, sched, N))
     b = t(lambda: ops.conv_fwd(xd, wd, None, N))
