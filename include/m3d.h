@@ -91,11 +91,16 @@ int m3d_subm_rulebook(const int32_t* d_indices, int64_t n, const int64_t spatial
  *   d_pair_bwd    [8,n]  i32  pair_bwd[k][i] = o or -1
  *   d_n_out       [1]    i64
  *   batch_size: SparseConvTensor.batch_size (every batch index must be < batch_size)
+ *   d_n_rows      [1]    i64  optional (NULL = all n rows): the number of valid rows of d_indices, read on
+ *                             the device; n is then the capacity.  Lets a chain of strided maps (each
+ *                             level's d_n_out feeding the next level's d_n_rows) be enqueued without a
+ *                             host read-back in between.
  */
-size_t m3d_strided_rulebook_workspace_bytes(int64_t n);
-int m3d_strided_rulebook(const int32_t* d_indices, int64_t n, const int64_t spatial_shape[3],
-                         int batch_size, int32_t* d_out_indices, int32_t* d_pair_fwd, int32_t* d_pair_bwd,
-                         int64_t* d_n_out, void* d_ws, size_t ws_bytes, void* stream);
+size_t m3d_strided_rulebook_workspace_bytes(int64_t n, const int64_t spatial_shape[3], int batch_size);
+int m3d_strided_rulebook(const int32_t* d_indices, int64_t n, const int64_t* d_n_rows,
+                         const int64_t spatial_shape[3], int batch_size, int32_t* d_out_indices,
+                         int32_t* d_pair_fwd, int32_t* d_pair_bwd, int64_t* d_n_out, void* d_ws, size_t ws_bytes,
+                         void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Tile schedule of a kernel map: the order in which the convolution kernel walks output rows.

@@ -23,8 +23,8 @@ SIGNATURES = {
                             _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "m3d_subm_rulebook_workspace_bytes": (_sz, [_i64]),
     "m3d_subm_rulebook": (_int, [_vp, _i64, ctypes.POINTER(_i64), _vp, _vp, _sz, _vp]),
-    "m3d_strided_rulebook_workspace_bytes": (_sz, [_i64]),
-    "m3d_strided_rulebook": (_int, [_vp, _i64, ctypes.POINTER(_i64), _int, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "m3d_strided_rulebook_workspace_bytes": (_sz, [_i64, ctypes.POINTER(_i64), _int]),
+    "m3d_strided_rulebook": (_int, [_vp, _i64, _vp, ctypes.POINTER(_i64), _int, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "m3d_schedule_npad": (_i64, [_i64]),
     "m3d_schedule_workspace_bytes": (_sz, [_i64]),
     "m3d_build_schedule": (_int, [_vp, _int, _i64, _i64, _vp, ctypes.POINTER(_i64), _int, _int, _vp,

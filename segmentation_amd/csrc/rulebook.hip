@@ -64,10 +64,14 @@ __global__ __launch_bounds__(256) void subm_probe_kernel(const int4* __restrict_
 
 // ------------------------------------------------------------------------------ strided k2 s2
 // Rows whose parent falls outside the output shape get `drop_key` = one past the largest valid key.
-__global__ void strided_key_kernel(const int4* __restrict__ idx, int64_t n, Shape3 out_sh,
-                                   uint64_t drop_key, uint64_t* __restrict__ keys) {
+__global__ void strided_key_kernel(const int4* __restrict__ idx, int64_t n, const int64_t* __restrict__ d_n,
+                                   Shape3 out_sh, uint64_t drop_key, uint64_t* __restrict__ keys) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  if (d_n && i >= *d_n) {  // capacity rows past the device-side row count
+    keys[i] = drop_key;
+    return;
+  }
   const int4 c = idx[i];
   const int x = c.y >> 1, y = c.z >> 1, z = c.w >> 1;
   const bool ok = x < out_sh.s[0] && y < out_sh.s[1] && z < out_sh.s[2];
@@ -107,6 +111,123 @@ __global__ void strided_outidx_kernel(const uint64_t* __restrict__ ukeys, const 
   const int y = (int)(r % (uint64_t)out_sh.s[1]); r /= (uint64_t)out_sh.s[1];
   const int x = (int)(r % (uint64_t)out_sh.s[0]); r /= (uint64_t)out_sh.s[0];
   out_idx[o] = make_int4((int)r, x, y, z);
+}
+
+// --- occupancy-bitmap variant: when batch * output volume is small enough, the set of output cells is a
+// bitmap over the linearised output grid; the rank of a set bit (prefix popcount) IS the output row,
+// because output rows are ordered by ascending linear index.  No hashing, no sorting.
+constexpr int kBitmapBlockWords = 1024;  // words per 256-thread block (4 per thread)
+
+__global__ void strided_mark_kernel(const int4* __restrict__ idx, int64_t n, const int64_t* __restrict__ d_n,
+                                    Shape3 out_sh, uint64_t cells, unsigned long long* __restrict__ bitmap) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || (d_n && i >= *d_n)) return;
+  const int4 c = idx[i];
+  const int x = c.y >> 1, y = c.z >> 1, z = c.w >> 1;
+  if (x >= out_sh.s[0] || y >= out_sh.s[1] || z >= out_sh.s[2]) return;
+  const uint64_t key = lin_key(c.x, x, y, z, out_sh);
+  if (key >= cells) return;  // batch index or coordinate out of range: never touch memory past the bitmap
+  atomicOr(&bitmap[key >> 6], 1ull << (key & 63));
+}
+
+// exclusive scan of one int per thread over a 256-thread block; returns the prefix, *total = block sum
+__device__ inline int block_exclusive_scan_256(int v, int* total) {
+  __shared__ int wsum[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int inc = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int t = __shfl_up(inc, d, 64);
+    if (lane >= d) inc += t;
+  }
+  __syncthreads();  // wsum may still be read by a previous call
+  if (lane == 63) wsum[wave] = inc;
+  __syncthreads();
+  int base = 0;
+  for (int w = 0; w < wave; ++w) base += wsum[w];
+  *total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+  return base + inc - v;
+}
+
+__global__ __launch_bounds__(256) void bitmap_block_sum_kernel(const unsigned long long* __restrict__ bitmap,
+                                                               int64_t nwords, int* __restrict__ bsum) {
+  const int64_t w0 = (int64_t)blockIdx.x * kBitmapBlockWords + threadIdx.x * 4;
+  int c = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if (w0 + j < nwords) c += __popcll(bitmap[w0 + j]);
+  int total;
+  block_exclusive_scan_256(c, &total);
+  if (threadIdx.x == 0) bsum[blockIdx.x] = total;
+}
+
+// one block: exclusive scan of the block sums in place, total -> *d_nout / *n_out64
+__global__ __launch_bounds__(256) void bitmap_scan_sums_kernel(int* __restrict__ bsum, int nb, int* __restrict__ d_nout,
+                                                               int64_t* __restrict__ n_out64) {
+  int carry = 0;
+  for (int base = 0; base < nb; base += 256) {
+    const int i = base + threadIdx.x;
+    const int v = i < nb ? bsum[i] : 0;
+    int total;
+    const int ex = block_exclusive_scan_256(v, &total);
+    if (i < nb) bsum[i] = carry + ex;
+    carry += total;
+  }
+  if (threadIdx.x == 0) {
+    *d_nout = carry;
+    *n_out64 = carry;
+  }
+}
+
+// per-word exclusive prefix, and the coordinates of every set bit
+__global__ __launch_bounds__(256) void bitmap_prefix_emit_kernel(const unsigned long long* __restrict__ bitmap,
+                                                                 int64_t nwords, const int* __restrict__ bsum,
+                                                                 int* __restrict__ prefix, Shape3 out_sh,
+                                                                 int4* __restrict__ out_idx) {
+  const int64_t w0 = (int64_t)blockIdx.x * kBitmapBlockWords + threadIdx.x * 4;
+  unsigned long long wv[4];
+  int c = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    wv[j] = w0 + j < nwords ? bitmap[w0 + j] : 0ull;
+    c += __popcll(wv[j]);
+  }
+  int total;
+  int o = bsum[blockIdx.x] + block_exclusive_scan_256(c, &total);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if (w0 + j >= nwords) break;
+    prefix[w0 + j] = o;
+    unsigned long long m = wv[j];
+    while (m) {
+      const int b = __ffsll((long long)m) - 1;
+      m &= m - 1;
+      uint64_t r = (uint64_t)(w0 + j) * 64 + (uint64_t)b;
+      const int z = (int)(r % (uint64_t)out_sh.s[2]); r /= (uint64_t)out_sh.s[2];
+      const int y = (int)(r % (uint64_t)out_sh.s[1]); r /= (uint64_t)out_sh.s[1];
+      const int x = (int)(r % (uint64_t)out_sh.s[0]); r /= (uint64_t)out_sh.s[0];
+      out_idx[o++] = make_int4((int)r, x, y, z);
+    }
+  }
+}
+
+__global__ void strided_pair_bitmap_kernel(const int4* __restrict__ idx, int64_t n, const int64_t* __restrict__ d_n,
+                                           Shape3 out_sh, uint64_t cells,
+                                           const unsigned long long* __restrict__ bitmap,
+                                           const int* __restrict__ prefix, int32_t* __restrict__ pair_fwd,
+                                           int32_t* __restrict__ pair_bwd) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || (d_n && i >= *d_n)) return;
+  const int4 c = idx[i];
+  const int x = c.y >> 1, y = c.z >> 1, z = c.w >> 1;
+  if (x >= out_sh.s[0] || y >= out_sh.s[1] || z >= out_sh.s[2]) return;
+  const uint64_t key = lin_key(c.x, x, y, z, out_sh);
+  if (key >= cells) return;
+  const unsigned long long w = bitmap[key >> 6];
+  const int o = prefix[key >> 6] + __popcll(w & ((1ull << (key & 63)) - 1));
+  const int k = ((c.y & 1) * 2 + (c.z & 1)) * 2 + (c.w & 1);
+  pair_fwd[(int64_t)k * n + o] = (int32_t)i;
+  pair_bwd[(int64_t)k * n + i] = o;
 }
 
 // ------------------------------------------------------------------------------ schedule
@@ -251,14 +372,36 @@ extern "C" int m3d_subm_rulebook(const int32_t* d_indices, int64_t n, const int6
   return M3D_OK;
 }
 
-extern "C" size_t m3d_strided_rulebook_workspace_bytes(int64_t n) {
+// Largest linearised output grid (cells) the occupancy-bitmap variant is used for: 32 MiB of bitmap.
+static const uint64_t kBitmapMaxCells = 1ull << 28;
+
+static bool strided_cells(const int64_t spatial_shape[3], int batch_size, uint64_t* cells) {
+  if (!spatial_shape || batch_size < 1) return false;
+  long double vol = (long double)batch_size;
+  for (int a = 0; a < 3; ++a) {
+    if (spatial_shape[a] <= 0) return false;
+    vol *= (long double)(spatial_shape[a] / 2);
+  }
+  if (!(vol < 9.0e18L)) return false;
+  *cells = (uint64_t)batch_size * (uint64_t)(spatial_shape[0] / 2) * (uint64_t)(spatial_shape[1] / 2) *
+           (uint64_t)(spatial_shape[2] / 2);
+  return true;
+}
+
+extern "C" size_t m3d_strided_rulebook_workspace_bytes(int64_t n, const int64_t spatial_shape[3], int batch_size) {
   if (n <= 0) n = 1;
+  uint64_t cells = 0;
+  if (strided_cells(spatial_shape, batch_size, &cells) && cells > 0 && cells <= kBitmapMaxCells) {
+    const uint64_t nwords = cdiv(cells, 64);
+    return align_up(nwords * sizeof(uint64_t)) + align_up(nwords * sizeof(int)) +
+           align_up(cdiv(nwords, kBitmapBlockWords) * sizeof(int)) + align_up(64 * sizeof(int));
+  }
   return align_up(n * sizeof(uint64_t)) * 2 + align_up(n * sizeof(int32_t)) * 2 +
          align_up(64 * sizeof(int)) * 2 + align_up(unique_ws_bytes(n));
 }
 
-extern "C" int m3d_strided_rulebook(const int32_t* d_indices, int64_t n, const int64_t spatial_shape[3],
-                                    int batch_size, int32_t* d_out_indices, int32_t* d_pair_fwd, int32_t* d_pair_bwd,
+extern "C" int m3d_strided_rulebook(const int32_t* d_indices, int64_t n, const int64_t* d_n_rows,
+                                    const int64_t spatial_shape[3], int batch_size, int32_t* d_out_indices, int32_t* d_pair_fwd, int32_t* d_pair_bwd,
                                     int64_t* d_n_out, void* d_ws, size_t ws_bytes, void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   M3D_CHECK_ARG(n > 0 && n < (int64_t)INT_MAX, "m3d_strided_rulebook: n out of range");
@@ -272,6 +415,34 @@ extern "C" int m3d_strided_rulebook(const int32_t* d_indices, int64_t n, const i
   const long double vol = (long double)batch_size * osh.s[0] * osh.s[1] * osh.s[2];
   M3D_CHECK_ARG(vol < 9.0e18L, "m3d_strided_rulebook: batch_size * output volume overflows 63 bits");
   const uint64_t drop_key = (uint64_t)batch_size * (uint64_t)osh.s[0] * (uint64_t)osh.s[1] * (uint64_t)osh.s[2];
+  const int bs = 256;
+  const unsigned gb = (unsigned)cdiv(n, bs);
+  const int4* idx = reinterpret_cast<const int4*>(d_indices);
+  if (drop_key <= kBitmapMaxCells) {
+    const int64_t nwords = (int64_t)cdiv(drop_key, 64);
+    const int nb = (int)cdiv(nwords, kBitmapBlockWords);
+    Arena a(d_ws, ws_bytes);
+    unsigned long long* bitmap = a.take<unsigned long long>(nwords);
+    int* prefix = a.take<int>(nwords);
+    int* bsum = a.take<int>(nb);
+    int* nout = a.take<int>(64);
+    if (!a.ok) {
+      set_error("m3d_strided_rulebook: workspace too small (%zu given, %zu needed)", ws_bytes, a.off);
+      return M3D_ENOSPC;
+    }
+    M3D_HIP(hipMemsetAsync(bitmap, 0, (size_t)nwords * sizeof(unsigned long long), stream));
+    M3D_HIP(hipMemsetAsync(d_pair_fwd, 0xFF, (size_t)8 * n * sizeof(int32_t), stream));
+    M3D_HIP(hipMemsetAsync(d_pair_bwd, 0xFF, (size_t)8 * n * sizeof(int32_t), stream));
+    hipLaunchKernelGGL(strided_mark_kernel, dim3(gb), dim3(bs), 0, stream, idx, n, d_n_rows, osh, drop_key, bitmap);
+    hipLaunchKernelGGL(bitmap_block_sum_kernel, dim3(nb), dim3(256), 0, stream, bitmap, nwords, bsum);
+    hipLaunchKernelGGL(bitmap_scan_sums_kernel, dim3(1), dim3(256), 0, stream, bsum, nb, nout, d_n_out);
+    hipLaunchKernelGGL(bitmap_prefix_emit_kernel, dim3(nb), dim3(256), 0, stream, bitmap, nwords, bsum, prefix, osh,
+                       reinterpret_cast<int4*>(d_out_indices));
+    hipLaunchKernelGGL(strided_pair_bitmap_kernel, dim3(gb), dim3(bs), 0, stream, idx, n, d_n_rows, osh, drop_key, bitmap, prefix,
+                       d_pair_fwd, d_pair_bwd);
+    M3D_LAUNCH_CHECK();
+    return M3D_OK;
+  }
   const int nbits = bits_for(drop_key);
   Arena a(d_ws, ws_bytes);
   uint64_t* keys = a.take<uint64_t>(n);
@@ -286,10 +457,7 @@ extern "C" int m3d_strided_rulebook(const int32_t* d_indices, int64_t n, const i
     set_error("m3d_strided_rulebook: workspace too small (%zu given, %zu needed)", ws_bytes, a.off);
     return M3D_ENOSPC;
   }
-  const int bs = 256;
-  const unsigned gb = (unsigned)cdiv(n, bs);
-  const int4* idx = reinterpret_cast<const int4*>(d_indices);
-  hipLaunchKernelGGL(strided_key_kernel, dim3(gb), dim3(bs), 0, stream, idx, n, osh, drop_key, keys);
+  hipLaunchKernelGGL(strided_key_kernel, dim3(gb), dim3(bs), 0, stream, idx, n, d_n_rows, osh, drop_key, keys);
   M3D_LAUNCH_CHECK();
   int rc = unique_sorted(keys, n, nbits, ukeys, rep, inverse, count, uws, ub, stream);
   if (rc != M3D_OK) return rc;

@@ -131,34 +131,34 @@ class SpUNetEngine:
         self.text_folded = _Conv(ops.pack_weight(wfold, self.precision), None, bfold.contiguous())
 
     # ------------------------------------------------------------------ kernel maps
-    def _build_level(self, l, idx, shape, batch_size):
-        lv = _Level()
-        lv.indices, lv.shape, lv.n = idx, shape, idx.shape[0]
-        lv.pair_subm = ops.subm_rulebook(idx, shape)
-        lv.subm = ops.build_schedule(lv.pair_subm, lv.n, idx, self.sched_modes[min(l, len(self.sched_modes) - 1)], shape,
-                                     batch_size)
-        lv.down = lv.up = lv.pair_fwd = lv.pair_bwd = None
-        lv.next_indices = lv.next_shape = None
-        lv.n_next = 0
-        if l < self.num_stages:
-            oi, oshape, pf, pb = ops.strided_rulebook(idx, shape, batch_size)
-            lv.pair_fwd, lv.pair_bwd = pf, pb
-            lv.down = ops.build_schedule(pf, oi.shape[0], None, 0)
-            lv.up = ops.build_schedule(pb, lv.n, None, 2, base_order=lv.subm.out_row)
-            lv.next_indices, lv.next_shape, lv.n_next = oi, oshape, oi.shape[0]
-        return lv
-
     def build_levels(self, voxel_coords, spatial_shape, batch_size=1):
-        """Kernel maps + tile schedules of every resolution level.  Level 0 rows arrive in hash order and
-        are walked in Morton order; deeper levels are already in row-major spatial order."""
+        """Kernel maps + tile schedules of every resolution level.  The chain of strided maps runs first, with the
+        row counts handed from level to level on the device and read back once; the submanifold maps and all
+        schedules are enqueued afterwards without any host read-back, so the host runs ahead of the GPU into
+        the network."""
         levels = []
+        chain = ops.strided_chain(voxel_coords, spatial_shape, batch_size, self.num_stages)
         idx, shape = voxel_coords, list(spatial_shape)
         for l in range(self.num_stages + 1):
-            lv = self._build_level(l, idx, shape, batch_size)
+            lv = _Level()
+            lv.indices, lv.shape, lv.n = idx, shape, idx.shape[0]
+            lv.down = lv.up = lv.pair_fwd = lv.pair_bwd = None
+            lv.next_indices = lv.next_shape = None
+            lv.n_next = 0
+            if l < self.num_stages:
+                oi, oshape, pf, pb = chain[l]
+                lv.pair_fwd, lv.pair_bwd = pf, pb
+                lv.next_indices, lv.next_shape, lv.n_next = oi, oshape, oi.shape[0]
             levels.append(lv)
             idx, shape = lv.next_indices, lv.next_shape
+        for l, lv in enumerate(levels):
+            lv.pair_subm = ops.subm_rulebook(lv.indices, lv.shape)
+            lv.subm = ops.build_schedule(lv.pair_subm, lv.n, lv.indices,
+                                         self.sched_modes[min(l, len(self.sched_modes) - 1)], lv.shape, batch_size)
+            if lv.pair_fwd is not None:
+                lv.down = ops.build_schedule(lv.pair_fwd, lv.n_next, None, 0)
+                lv.up = ops.build_schedule(lv.pair_bwd, lv.n, None, 2, base_order=lv.subm.out_row)
         return levels
-
 
     # ------------------------------------------------------------------ network
     # Activations travel as (f32 tensor or None, SplitTensor or None).  With precision "f32" only the f32

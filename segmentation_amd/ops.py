@@ -123,9 +123,11 @@ def subm_rulebook(indices, spatial_shape):
     return pair
 
 
-def strided_rulebook(indices, spatial_shape, batch_size):
-    """k2 s2 p0 kernel map (v1m3:154-161).  Returns out_indices [M,4], out_shape, pair_fwd [8,M]
-    (a strided view), pair_bwd [8,N]."""
+def strided_chain(indices, spatial_shape, batch_size, depth):
+    """`depth` successive k2 s2 p0 kernel maps (v1m3:154-161), each on the previous one's outputs.  The
+    output count of a level stays on the device and feeds the next level, so the whole chain is enqueued
+    without a host read-back; the counts are read once at the end.  Returns a list of
+    (out_indices [M,4], out_shape, pair_fwd [8,M] (a strided view), pair_bwd [8,N])."""
     lib = _lib.load()
     _need_cuda(indices)
     indices = indices.contiguous()
@@ -134,17 +136,34 @@ def strided_rulebook(indices, spatial_shape, batch_size):
     if n == 0:
         raise ValueError("strided_rulebook needs at least one voxel")
     dev = indices.device
-    out_idx = torch.empty((n, 4), dtype=torch.int32, device=dev)
-    pf = torch.empty((8, n), dtype=torch.int32, device=dev)
-    pb = torch.empty((8, n), dtype=torch.int32, device=dev)
-    nout = torch.empty((1,), dtype=torch.int64, device=dev)
-    ws = _workspace(lib.m3d_strided_rulebook_workspace_bytes(n), dev)
-    rc = lib.m3d_strided_rulebook(_ptr(indices), n, _shape3(spatial_shape), int(batch_size), _ptr(out_idx), _ptr(pf),
-                                  _ptr(pb), _ptr(nout), _ptr(ws), ws.numel(), _stream())
-    _lib.check(rc, "m3d_strided_rulebook")
-    m = int(nout.item())
-    out_shape = [int(s) // 2 for s in spatial_shape]
-    return out_idx[:m], out_shape, pf[:, :m], pb
+    counts = torch.empty((depth,), dtype=torch.int64, device=dev)
+    bufs, shape, cur = [], [int(s) for s in spatial_shape], indices
+    for l in range(depth):
+        out_idx = torch.empty((n, 4), dtype=torch.int32, device=dev)
+        pf = torch.empty((8, n), dtype=torch.int32, device=dev)
+        pb = torch.empty((8, n), dtype=torch.int32, device=dev)
+        ws = _workspace(lib.m3d_strided_rulebook_workspace_bytes(n, _shape3(shape), int(batch_size)), dev)
+        d_n_rows = counts[l - 1:l].data_ptr() if l else None
+        rc = lib.m3d_strided_rulebook(_ptr(cur), n, d_n_rows, _shape3(shape), int(batch_size), _ptr(out_idx), _ptr(pf),
+                                      _ptr(pb), counts[l:l + 1].data_ptr(), _ptr(ws), ws.numel(), _stream())
+        _lib.check(rc, "m3d_strided_rulebook")
+        shape = [s // 2 for s in shape]
+        bufs.append((out_idx, list(shape), pf, pb))
+        cur = out_idx
+    m = counts.cpu().tolist()  # the one host sync of the chain
+    out, n_in = [], n
+    for l, (out_idx, oshape, pf, pb) in enumerate(bufs):
+        if m[l] == 0:
+            raise ValueError(f"strided_rulebook: level {l} has no output voxel")
+        out.append((out_idx[:m[l]], oshape, pf[:, :m[l]], pb[:, :n_in]))
+        n_in = m[l]
+    return out
+
+
+def strided_rulebook(indices, spatial_shape, batch_size):
+    """k2 s2 p0 kernel map (v1m3:154-161).  Returns out_indices [M,4], out_shape, pair_fwd [8,M]
+    (a strided view), pair_bwd [8,N]."""
+    return strided_chain(indices, spatial_shape, batch_size, 1)[0]
 
 
 @dataclass

@@ -58,6 +58,20 @@ def test_strided_rulebook_drops_rows_outside_the_output_shape(device):
     assert np.array_equal(pb.cpu().numpy(), rpb)
 
 
+def test_strided_rulebook_large_grid_uses_the_sort_path(device):
+    # output grid of 2048^3 cells: too large for the occupancy bitmap, the hash + sort variant runs
+    rng = np.random.default_rng(5)
+    base = rng.integers(0, 4090, size=(3000, 3))
+    pts = np.concatenate([base, base + rng.integers(0, 2, size=base.shape), base[:500]], 0)
+    idx = np.concatenate([rng.integers(0, 2, size=(len(pts), 1)), pts], 1).astype(np.int32)
+    idx = np.unique(idx, axis=0)
+    idx = idx[rng.permutation(len(idx))]
+    oi, oshape, pf, pb = ops.strided_rulebook(torch.from_numpy(idx).to(device), [4096, 4096, 4096], 2)
+    roi, roshape, rpf, rpb = oracle.strided_rulebook(idx, [4096, 4096, 4096])
+    assert oshape == roshape and np.array_equal(oi.cpu().numpy(), roi)
+    assert np.array_equal(pf.cpu().numpy(), rpf) and np.array_equal(pb.cpu().numpy(), rpb)
+
+
 @pytest.mark.parametrize("mode", [0, 1, 2, 3])
 def test_schedule_is_a_permutation_of_the_kernel_map(device, mode):
     sp = _voxels(3, 9000)
