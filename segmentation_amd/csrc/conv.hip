@@ -551,7 +551,7 @@ struct DmaGeom {
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
-template <int WM, int WN, int NT, int T>
+template <int WM, int WN, int NT, int T, int NBUF>
 __device__ __forceinline__ void conv_igemm_dma_body(const ConvArgs& a) {
   using G = DmaGeom<T>;
   constexpr int BM = 32 * WM, BN = 32 * NT * WN, NTHR = 64 * WM * WN;
@@ -560,7 +560,7 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvArgs& a) {
   constexpr int GRPB = G::PIECES * 16;  // bytes of one (row, 32-channel group) in HBM
   static_assert(BM * G::SLOTS % NTHR == 0 && BN * G::SLOTS % NTHR == 0, "every wave must issue the same DMA count");
   extern __shared__ __align__(16) char ldsb[];
-  int* idx_s = reinterpret_cast<int*>(ldsb + 2 * BUF);  // [kvol][BM]
+  int* idx_s = reinterpret_cast<int*>(ldsb + NBUF * BUF);  // [kvol][BM]
   int* orow_s = idx_s + a.kvol * BM;
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -674,6 +674,9 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvArgs& a) {
 
   auto compute = [&](int bi) {
     const char* buf = ldsb + bi * BUF;
+    // products (activation term, weight term), smallest first: T = 2 -> (0,1) (1,0) (0,0); T = 3 adds (0,2) (2,0) (1,1)
+    constexpr int NP = T == 2 ? 3 : 6;
+    constexpr int pa[6] = {0, 2, 1, 0, 1, 0}, pb[6] = {2, 0, 1, 1, 0, 0};
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       bf16x8 af[T];
@@ -684,48 +687,46 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvArgs& a) {
         bf16x8 bf[T];
 #pragma unroll
         for (int t = 0; t < T; ++t) bf[t] = *reinterpret_cast<const bf16x8*>(buf + w_off[nt][ks][t]);
-        if (T == 3) {
-          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[T - 1], acc[nt], 0, 0, 0);
-          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[T - 1], bf[0], acc[nt], 0, 0, 0);
-          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[1], acc[nt], 0, 0, 0);
-        }
-        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[1], acc[nt], 0, 0, 0);
-        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[0], acc[nt], 0, 0, 0);
-        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[0], acc[nt], 0, 0, 0);
+#pragma unroll
+        for (int q = 6 - NP; q < 6; ++q)
+          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[pa[q]], bf[pb[q]], acc[nt], 0, 0, 0);
       }
     }
   };
 
   if (nstage > 0) {
-    issue_next(0);
-    if (nstage > 1) issue_next(1);
+    // Ring of NBUF buffers, stage s lives in buffer s % NBUF.  The requests of stages s + 1 .. s + NBUF - 2
+    // may still be in flight when stage s is consumed; the buffer that stage s - 1 just released receives
+    // stage s + NBUF - 1.  One barrier per stage: it publishes stage s to every wave and, because every wave
+    // has then finished reading stage s - 1, frees that buffer.
+    constexpr int G = A_V + W_V;  // DMA instructions per wave and stage
+    static_assert((NBUF - 2) * G < 64, "vmcnt is a 6-bit counter");
+#pragma unroll
+    for (int u = 0; u < NBUF - 1; ++u)
+      if (u < nstage) issue_next(u);
     uint32_t crem = bmask;
     int ck = __builtin_ctz(crem), ccc = 0;
-// one step: stage S lives in buffer BI; afterwards the buffer is refilled with stage S + 2
-#define M3D_DMA_STEP(S, BI)                                                                   \
-  {                                                                                           \
-    if ((S) + 1 < nstage) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_V + W_V) : "memory");    \
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                     \
-    __builtin_amdgcn_s_barrier();                                                             \
-    asm volatile("" ::: "memory");                                                            \
-    if (((wmask >> ck) & 1u) && !(a.dbg & 1)) compute(BI);                                    \
-    if (++ccc == nchunk) {                                                                    \
-      ccc = 0;                                                                                \
-      crem &= crem - 1;                                                                       \
-      ck = crem ? __builtin_ctz(crem) : ck;                                                   \
-    }                                                                                         \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                        \
-    __builtin_amdgcn_s_barrier();                                                             \
-    asm volatile("" ::: "memory");                                                            \
-    if (issued < nstage) issue_next(BI);                                                      \
-  }
-    int s = 0;
-    for (; s + 1 < nstage; s += 2) {
-      M3D_DMA_STEP(s, 0)
-      M3D_DMA_STEP(s + 1, 1)
+    for (int s0 = 0; s0 < nstage; s0 += NBUF) {
+#pragma unroll
+      for (int u = 0; u < NBUF; ++u) {
+        const int s = s0 + u;
+        if (s >= nstage) break;
+        const int ahead = nstage - 1 - s;  // stages issued after s (at most NBUF - 2 of them)
+        if (NBUF >= 4 && ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF >= 4 ? 2 : 0) * G) : "memory");
+        else if (NBUF >= 3 && ahead >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF >= 3 ? 1 : 0) * G) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (issued < nstage) issue_next((u + NBUF - 1) % NBUF);
+        if (((wmask >> ck) & 1u) && !(a.dbg & 1)) compute(u);
+        if (++ccc == nchunk) {
+          ccc = 0;
+          crem &= crem - 1;
+          ck = crem ? __builtin_ctz(crem) : ck;
+        }
+      }
     }
-    if (s < nstage) M3D_DMA_STEP(s, 0)
-#undef M3D_DMA_STEP
   }
   if (a.slab || (a.dbg & 32)) {
     conv_epilogue<NT>(a, acc, orow_s, tile_base, col_base, wm, wn, lane);
@@ -735,9 +736,9 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvArgs& a) {
   }
 }
 
-template <int WM, int WN, int NT, int T>
+template <int WM, int WN, int NT, int T, int NBUF>
 __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_dma_kernel(ConvArgs a) {
-  conv_igemm_dma_body<WM, WN, NT, T>(a);
+  conv_igemm_dma_body<WM, WN, NT, T, NBUF>(a);
 }
 
 // f32 [n][c] -> sf32 [n + 1][c/32][terms][32] bf16 (row n zero).  One thread per element.
@@ -938,21 +939,40 @@ static int launch_split(const ConvArgs& a, int nz, hipStream_t stream) {
   return M3D_OK;
 }
 
-template <int WM, int WN, int NT, int T>
-static int launch_dma(const ConvArgs& a, int nz, hipStream_t stream) {
+template <int WM, int WN, int NT, int T, int NBUF>
+static int launch_dma_n(const ConvArgs& a, int nz, hipStream_t stream) {
   constexpr int BM = 32 * WM, BN = 32 * NT * WN, NTHR = 64 * WM * WN;
-  static_assert((size_t)BM * BN * sizeof(float) <= (size_t)2 * (BM + BN) * DmaGeom<T>::ROWB, "output tile must fit in the staging buffers");
-  const size_t lds = (size_t)2 * (BM + BN) * DmaGeom<T>::ROWB + (size_t)(a.kvol + 1) * BM * sizeof(int);
+  static_assert((size_t)BM * BN * sizeof(float) <= (size_t)NBUF * (BM + BN) * DmaGeom<T>::ROWB, "output tile must fit in the staging buffers");
+  const size_t lds = (size_t)NBUF * (BM + BN) * DmaGeom<T>::ROWB + (size_t)(a.kvol + 1) * BM * sizeof(int);
   static size_t attr_lds = 0;
   if (lds > attr_lds) {
-    M3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_dma_kernel<WM, WN, NT, T>),
+    M3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_dma_kernel<WM, WN, NT, T, NBUF>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_lds = lds;
   }
   dim3 grid((unsigned)(a.npad / BM), (unsigned)(a.cout / BN), (unsigned)nz);
-  hipLaunchKernelGGL((conv_igemm_dma_kernel<WM, WN, NT, T>), grid, dim3(NTHR), lds, stream, a);
+  hipLaunchKernelGGL((conv_igemm_dma_kernel<WM, WN, NT, T, NBUF>), grid, dim3(NTHR), lds, stream, a);
   M3D_LAUNCH_CHECK();
   return M3D_OK;
+}
+
+// Ring depth: as deep as 160 KB of LDS allow (experiment hook: M3D_NBUF).
+template <int WM, int WN, int NT, int T>
+static int launch_dma(const ConvArgs& a, int nz, hipStream_t stream) {
+  constexpr int BM = 32 * WM, BN = 32 * NT * WN;
+  static const int want = [] {
+    const char* e = getenv("M3D_NBUF");
+    return e ? atoi(e) : 2;
+  }();
+  const size_t per_buf = (size_t)(BM + BN) * DmaGeom<T>::ROWB, idx = (size_t)(a.kvol + 1) * BM * sizeof(int);
+  int nbuf = want;
+  while (nbuf > 2 && nbuf * per_buf + idx > 160 * 1024) --nbuf;
+  constexpr int G = (BM + BN) * DmaGeom<T>::SLOTS / (64 * WM * WN);  // DMA instructions per wave and stage
+  if constexpr (2 * G < 64)
+    if (nbuf >= 4) return launch_dma_n<WM, WN, NT, T, 4>(a, nz, stream);
+  if constexpr (G < 64)
+    if (nbuf >= 3) return launch_dma_n<WM, WN, NT, T, 3>(a, nz, stream);
+  return launch_dma_n<WM, WN, NT, T, 2>(a, nz, stream);
 }
 
 // Tile configuration: the largest row tile that still yields >= ~2 workgroups per CU.
@@ -960,7 +980,7 @@ struct ConvPlan {
   int wm, wn, nt, nz;
 };
 
-static ConvPlan plan_conv(int64_t npad, int cout, int kvol) {
+static ConvPlan plan_conv(int64_t npad, int cout, int kvol, int cin) {
   int bn;
   if (cout % 128 == 0) bn = 128;
   else if (cout % 96 == 0) bn = 96;
@@ -976,6 +996,9 @@ static ConvPlan plan_conv(int64_t npad, int cout, int kvol) {
     if (bn == 96) return ConvPlan{2, 1, 3, 1};
     return ConvPlan{2, 1, 1, 1};
   }
+  // small level, long reduction (>= 8 channel slabs per offset): full-height tiles amortise the weight
+  // stream, the kernel offsets are split 9 ways for parallelism
+  if (kvol == 27 && cin >= 256 && (npad / 128) * ncol * 9 >= 256) return ConvPlan{4, 1, bn / 32, 9};
   p = ConvPlan{1, bn / 32, 1, 1};
   const int64_t blocks = (npad / 32) * ncol;
   if (blocks < target && kvol > 1) {
@@ -994,9 +1017,10 @@ using namespace m3d;
 extern "C" size_t m3d_conv_workspace_bytes(int64_t n, int cout, int k) {
   const int64_t npad = m3d_schedule_npad(n);
   if (cout <= 0 || cout % 32 != 0) return 256;  // served by the direct kernel, which needs no scratch
-  ConvPlan p = plan_conv(npad, cout, k);
-  if (p.nz <= 1) return 256;
-  return align_up((size_t)p.nz * npad * cout * sizeof(float));
+  const int nz_short = plan_conv(npad, cout, k, 32).nz, nz_long = plan_conv(npad, cout, k, 1 << 20).nz;
+  const int nz = nz_short > nz_long ? nz_short : nz_long;  // the plan also depends on the input channels
+  if (nz <= 1) return 256;
+  return align_up((size_t)nz * npad * cout * sizeof(float));
 }
 
 // mode: 0 exact f32, 1/2 split-bf16 with in-kernel activation split (T = 2/3), 3/4 LDS-DMA on sf32 inputs (T = 2/3)
@@ -1026,7 +1050,7 @@ static int run_conv(ConvArgs& a, int mode, bool mfma_ok, void* d_ws, size_t ws_b
     M3D_LAUNCH_CHECK();
     return M3D_OK;
   }
-  ConvPlan p = plan_conv(a.npad, a.cout, a.kvol);
+  ConvPlan p = plan_conv(a.npad, a.cout, a.kvol, a.c0 + a.c1);
   if (mode >= 3 && p.wm == 1 && p.wn == 3) p = ConvPlan{1, 1, 3, p.nz};  // equal DMA count per wave
   if (p.nz > 1) {
     const size_t need = (size_t)p.nz * a.npad * a.cout * sizeof(float);

@@ -127,7 +127,9 @@ __global__ void strided_mark_kernel(const int4* __restrict__ idx, int64_t n, con
   if (x >= out_sh.s[0] || y >= out_sh.s[1] || z >= out_sh.s[2]) return;
   const uint64_t key = lin_key(c.x, x, y, z, out_sh);
   if (key >= cells) return;  // batch index or coordinate out of range: never touch memory past the bitmap
-  atomicOr(&bitmap[key >> 6], 1ull << (key & 63));
+  const unsigned long long bit = 1ull << (key & 63);
+  // up to 8 children share a cell: most find the bit already set and skip the atomic
+  if (!(__builtin_nontemporal_load(&bitmap[key >> 6]) & bit)) atomicOr(&bitmap[key >> 6], bit);
 }
 
 // exclusive scan of one int per thread over a 256-thread block; returns the prefix, *total = block sum
@@ -179,35 +181,23 @@ __global__ __launch_bounds__(256) void bitmap_scan_sums_kernel(int* __restrict__
   }
 }
 
-// per-word exclusive prefix, and the coordinates of every set bit
-__global__ __launch_bounds__(256) void bitmap_prefix_emit_kernel(const unsigned long long* __restrict__ bitmap,
-                                                                 int64_t nwords, const int* __restrict__ bsum,
-                                                                 int* __restrict__ prefix, Shape3 out_sh,
-                                                                 int4* __restrict__ out_idx) {
+// per-word exclusive prefix of the set-bit counts
+__global__ __launch_bounds__(256) void bitmap_prefix_kernel(const unsigned long long* __restrict__ bitmap,
+                                                            int64_t nwords, const int* __restrict__ bsum,
+                                                            int* __restrict__ prefix) {
   const int64_t w0 = (int64_t)blockIdx.x * kBitmapBlockWords + threadIdx.x * 4;
-  unsigned long long wv[4];
-  int c = 0;
+  int cnt[4], c = 0;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    wv[j] = w0 + j < nwords ? bitmap[w0 + j] : 0ull;
-    c += __popcll(wv[j]);
+    cnt[j] = w0 + j < nwords ? __popcll(bitmap[w0 + j]) : 0;
+    c += cnt[j];
   }
   int total;
   int o = bsum[blockIdx.x] + block_exclusive_scan_256(c, &total);
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    if (w0 + j >= nwords) break;
-    prefix[w0 + j] = o;
-    unsigned long long m = wv[j];
-    while (m) {
-      const int b = __ffsll((long long)m) - 1;
-      m &= m - 1;
-      uint64_t r = (uint64_t)(w0 + j) * 64 + (uint64_t)b;
-      const int z = (int)(r % (uint64_t)out_sh.s[2]); r /= (uint64_t)out_sh.s[2];
-      const int y = (int)(r % (uint64_t)out_sh.s[1]); r /= (uint64_t)out_sh.s[1];
-      const int x = (int)(r % (uint64_t)out_sh.s[0]); r /= (uint64_t)out_sh.s[0];
-      out_idx[o++] = make_int4((int)r, x, y, z);
-    }
+    if (w0 + j < nwords) prefix[w0 + j] = o;
+    o += cnt[j];
   }
 }
 
@@ -215,7 +205,7 @@ __global__ void strided_pair_bitmap_kernel(const int4* __restrict__ idx, int64_t
                                            Shape3 out_sh, uint64_t cells,
                                            const unsigned long long* __restrict__ bitmap,
                                            const int* __restrict__ prefix, int32_t* __restrict__ pair_fwd,
-                                           int32_t* __restrict__ pair_bwd) {
+                                           int32_t* __restrict__ pair_bwd, int4* __restrict__ out_idx) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n || (d_n && i >= *d_n)) return;
   const int4 c = idx[i];
@@ -228,6 +218,7 @@ __global__ void strided_pair_bitmap_kernel(const int4* __restrict__ idx, int64_t
   const int k = ((c.y & 1) * 2 + (c.z & 1)) * 2 + (c.w & 1);
   pair_fwd[(int64_t)k * n + o] = (int32_t)i;
   pair_bwd[(int64_t)k * n + i] = o;
+  out_idx[o] = make_int4(c.x, x, y, z);  // every child of the cell writes the same value
 }
 
 // ------------------------------------------------------------------------------ schedule
@@ -436,10 +427,9 @@ extern "C" int m3d_strided_rulebook(const int32_t* d_indices, int64_t n, const i
     hipLaunchKernelGGL(strided_mark_kernel, dim3(gb), dim3(bs), 0, stream, idx, n, d_n_rows, osh, drop_key, bitmap);
     hipLaunchKernelGGL(bitmap_block_sum_kernel, dim3(nb), dim3(256), 0, stream, bitmap, nwords, bsum);
     hipLaunchKernelGGL(bitmap_scan_sums_kernel, dim3(1), dim3(256), 0, stream, bsum, nb, nout, d_n_out);
-    hipLaunchKernelGGL(bitmap_prefix_emit_kernel, dim3(nb), dim3(256), 0, stream, bitmap, nwords, bsum, prefix, osh,
-                       reinterpret_cast<int4*>(d_out_indices));
+    hipLaunchKernelGGL(bitmap_prefix_kernel, dim3(nb), dim3(256), 0, stream, bitmap, nwords, bsum, prefix);
     hipLaunchKernelGGL(strided_pair_bitmap_kernel, dim3(gb), dim3(bs), 0, stream, idx, n, d_n_rows, osh, drop_key, bitmap, prefix,
-                       d_pair_fwd, d_pair_bwd);
+                       d_pair_fwd, d_pair_bwd, reinterpret_cast<int4*>(d_out_indices));
     M3D_LAUNCH_CHECK();
     return M3D_OK;
   }

@@ -11,7 +11,8 @@ n = sc["coord"].shape[0]
 vox = ops.voxelize(torch.from_numpy(sc["coord"]).to(dev), torch.from_numpy(sc["feat"]).to(dev), np.array([0, n]), 0.02)
 idx = vox["voxel_coords"]; N = idx.shape[0]
 pair = ops.subm_rulebook(idx, vox["spatial_shape"])
-sched = ops.build_schedule(pair, N, idx, 1, vox["spatial_shape"], 1)
+SMODE = int(os.environ.get("SMODE", "1539"))
+sched = ops.build_schedule(pair, N, idx, SMODE, vox["spatial_shape"], 1)
 x = torch.randn(N, cin, device=dev); w = ops.pack_weight(torch.randn(cout, 27, cin) * 0.03, prec, dev)
 xd = torch.randn(N, 768, device=dev); wd = ops.pack_weight(torch.randn(256, 1, 768) * 0.03, prec, dev)
 if len(sys.argv) > 2 and sys.argv[2] == "dma":
