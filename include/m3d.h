@@ -166,9 +166,28 @@ int m3d_conv_fwd_f32(const float* d_in0, int c0, const float* d_in1, int c1,
 int m3d_conv_fwd_sf32(const void* d_in0, int c0, int64_t rows0, const void* d_in1, int c1,
                       int64_t rows1, const void* d_weight, int k, int cout, const int32_t* d_nbr,
                       const int32_t* d_out_row, const uint32_t* d_tile_mask, int64_t n, int64_t npad,
-                      const float* d_scale, const float* d_shift, const float* d_residual, int relu,
+                      const int32_t* d_halo_cnt, const int32_t* d_halo_rows, const uint16_t* d_halo_loc,
+                      const int32_t* d_halo_order, const float* d_scale, const float* d_shift, const float* d_residual, int relu,
                       float* d_out, int64_t ldo, void* d_out_split, int terms, void* d_ws,
                       size_t ws_bytes, void* stream);
+
+/* Halo of a tile schedule (optional accelerator of m3d_conv_fwd_sf32 with terms = 2, meant for 3x3x3
+ * submanifold maps of large levels).  For every tile of m3d_halo_tile_rows() = 256 schedule rows: the
+ * distinct input rows its pairs reference (at most m3d_halo_cap() = 640; a tile with more is marked -1
+ * and convolved offset by offset) and, per pair, the index of its input row in that list.  With a halo
+ * the convolution loads each distinct input row once per 32-channel slab instead of once per kernel offset.
+ *   d_nbr [k,npad], d_out_row [npad]: from m3d_build_schedule (npad is a multiple of 256)
+ *   order_by_schedule != 0 (submanifold maps: input rows = output rows; needs n_in = rows and a
+ *     workspace of n_in * 4 bytes): halo rows are listed in schedule order, which keeps the LDS reads of
+ *     neighbouring rows on distinct banks; 0: listed by row index
+ *   d_halo_cnt [npad/256] i32, d_halo_rows [npad/256, 640] i32, d_halo_loc [npad/256, k, 256] u16,
+ *   d_halo_order [npad/256] i32: the order in which the convolution grid takes the tiles (-1 tiles first)
+ * No counterpart in the reference. */
+int m3d_halo_cap(void);
+int m3d_halo_tile_rows(void);
+int m3d_build_halo(const int32_t* d_nbr, const int32_t* d_out_row, int k, int64_t npad, int64_t n_in,
+                   int order_by_schedule, int32_t* d_halo_cnt, int32_t* d_halo_rows, uint16_t* d_halo_loc,
+                   int32_t* d_halo_order, void* d_ws, size_t ws_bytes, void* stream);
 size_t m3d_sf32_bytes(int64_t n, int c, int terms);
 int m3d_split_f32(const float* d_in, int64_t n, int c, int terms, void* d_out, void* stream);
 

@@ -6,7 +6,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libm3d_hip.so")
+LIB_PATH = os.environ.get("M3D_LIB_PATH") or os.path.join(_HERE, "libm3d_hip.so")  # override: experiment builds
 
 _vp = ctypes.c_void_p
 _i64 = ctypes.c_int64
@@ -33,7 +33,10 @@ SIGNATURES = {
     "m3d_conv_fwd_f32": (_int, [_vp, _int, _vp, _int, _vp, _int, _int, _vp, _vp, _vp, _i64, _i64,
                                 _vp, _vp, _vp, _int, _vp, _i64, _vp, _int, _int, _vp, _sz, _vp]),
     "m3d_conv_fwd_sf32": (_int, [_vp, _int, _i64, _vp, _int, _i64, _vp, _int, _int, _vp, _vp, _vp, _i64, _i64,
-                                 _vp, _vp, _vp, _int, _vp, _i64, _vp, _int, _vp, _sz, _vp]),
+                                 _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _vp, _i64, _vp, _int, _vp, _sz, _vp]),
+    "m3d_halo_cap": (_int, []),
+    "m3d_halo_tile_rows": (_int, []),
+    "m3d_build_halo": (_int, [_vp, _vp, _int, _i64, _i64, _int, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "m3d_sf32_bytes": (_sz, [_i64, _int, _int]),
     "m3d_split_f32": (_int, [_vp, _i64, _int, _int, _vp, _vp]),
     "m3d_conv_packed_weight_bytes": (_sz, [_int, _int, _int, _int]),

@@ -18,198 +18,12 @@
 //
 // HBM/L2 layout: activations [rows, C] f32 row-major (a gathered row slab is one full 128-B
 // line), weights [k][Cout][Cin] so that a weight slab is also 128 B per output channel.
-#include "common.h"
+#include "conv_shared.h"
 
 #include <stdlib.h>
 
 namespace m3d {
 
-typedef float floatx16 __attribute__((ext_vector_type(16)));
-
-struct ConvArgs {
-  const float* in0;
-  const float* in1;
-  const float* weight;
-  const int32_t* nbr;
-  const int32_t* out_row;
-  const uint32_t* tile_mask;
-  const float* scale;
-  const float* shift;
-  const float* residual;
-  float* out;
-  float* slab;  // split-K partial sums [z][npad][cout], or nullptr
-  int64_t n, npad, ldo;
-  int c0, c1, cout, kvol, relu;
-  int dbg;  // timing-only ablation bits (M3D_DBG); 0 in normal operation
-  // split-format ("sf32") operands of the LDS-DMA kernel: [rows + 1][C/32][T][32] bf16, last row zero
-  const char* s0;
-  const char* s1;
-  int64_t zero0, zero1;  // index of the all-zero row of s0 / s1
-  char* out_split;       // optional sf32 copy of the output (cout/32 groups per row)
-  int terms;             // T of out_split
-};
-
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-
-// One element of an sf32 tensor: term t = bf16 rounding of what the earlier terms left over.
-__device__ inline void store_split(char* base, int64_t row, int col, int c, int terms, float v) {
-  __bf16* p = reinterpret_cast<__bf16*>(base + ((row * (c >> 5) + (col >> 5)) * terms) * 64) + (col & 31);
-  for (int t = 0; t < terms; ++t) {
-    const __bf16 q = (__bf16)v;
-    p[t * 32] = q;
-    v -= (float)q;
-  }
-}
-
-// The all-zero row (index n) of an sf32 output; called by one workgroup of the kernel that writes the output.
-__device__ inline void clear_zero_row(const ConvArgs& a) {
-  if (a.out_split == nullptr) return;
-  const int words = a.cout * a.terms / 2;  // 4-byte words in one row
-  uint32_t* p = reinterpret_cast<uint32_t*>(a.out_split + (int64_t)a.n * a.cout * a.terms * 2);
-  for (int i = threadIdx.x; i < words; i += blockDim.x) p[i] = 0u;
-}
-
-// Accumulator register r of a 32x32 tile is row (r&3) + 8*(r>>2) + 4*(lane>>5), column lane&31.
-template <int NT>
-__device__ inline void conv_epilogue(const ConvArgs& a, const floatx16 (&acc)[NT], const int* orow_s,
-                                     int64_t tile_base, int col_base, int wm, int wn, int lane) {
-  const int h = lane >> 5, cl = lane & 31;
-  if (a.slab) {
-    float* dst = a.slab + ((int64_t)blockIdx.z * a.npad + tile_base + wm * 32) * a.cout + col_base;
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const int col = (wn * NT + nt) * 32 + cl;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int rl = (r & 3) + 8 * (r >> 2) + 4 * h;
-        dst[(int64_t)rl * a.cout + col] = acc[nt][r];
-      }
-    }
-    return;
-  }
-  if (blockIdx.x == 0 && blockIdx.y == 0) clear_zero_row(a);
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    const int col = col_base + (wn * NT + nt) * 32 + cl;
-    const float sc = a.scale ? a.scale[col] : 1.f;
-    const float sh = a.shift ? a.shift[col] : 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int rl = (r & 3) + 8 * (r >> 2) + 4 * h;
-      const int orow = orow_s[wm * 32 + rl];
-      if (orow >= 0) {
-        float v = acc[nt][r] * sc + sh;
-        if (a.residual) v += a.residual[(int64_t)orow * a.cout + col];
-        if (a.relu) v = fmaxf(v, 0.f);
-        if (a.out) a.out[(int64_t)orow * a.ldo + col] = v;
-        if (a.out_split) store_split(a.out_split, orow, col, a.cout, a.terms, v);
-      }
-    }
-  }
-}
-
-// Epilogue through an LDS image of the output tile: the accumulators (with the per-channel affine
-// applied) are written to S[BM][BN] f32, then every thread finishes 8 consecutive channels of one row
-// (residual, ReLU) and stores them with 16/32-byte accesses: f32 row segment and/or the sf32 terms.
-template <int WM, int WN, int NT>
-__device__ inline void conv_epilogue_staged(const ConvArgs& a, const floatx16 (&acc)[NT], const int* orow_s,
-                                            float* S, int col_base, int wm, int wn, int lane, int tid) {
-  constexpr int BM = 32 * WM, BN = 32 * NT * WN, NTHR = 64 * WM * WN;
-  const int h = lane >> 5, cl = lane & 31;
-  if (blockIdx.x == 0 && blockIdx.y == 0) clear_zero_row(a);
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    const int lc = (wn * NT + nt) * 32 + cl;
-    const float sc = a.scale ? a.scale[col_base + lc] : 1.f;
-    const float sh = a.shift ? a.shift[col_base + lc] : 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int rl = (r & 3) + 8 * (r >> 2) + 4 * h;
-      S[(wm * 32 + rl) * BN + lc] = acc[nt][r] * sc + sh;
-    }
-  }
-  __syncthreads();
-  constexpr int CPR = BN / 4;  // 4-channel pieces per row: consecutive lanes store consecutive 16 B (f32) / 8 B (bf16)
-  for (int e = tid; e < BM * CPR; e += NTHR) {
-    const int r = e / CPR, c4 = e % CPR;
-    const int orow = orow_s[r];
-    if (orow < 0) continue;
-    const float4 v0 = *reinterpret_cast<const float4*>(S + r * BN + c4 * 4);
-    float v[4] = {v0.x, v0.y, v0.z, v0.w};
-    const int col = col_base + c4 * 4;
-    if (a.residual) {
-      const float4 q0 = *reinterpret_cast<const float4*>(a.residual + (int64_t)orow * a.cout + col);
-      v[0] += q0.x; v[1] += q0.y; v[2] += q0.z; v[3] += q0.w;
-    }
-    if (a.relu) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
-    }
-    if (a.out) {
-      float* o = a.out + (int64_t)orow * a.ldo + col;
-      if ((a.ldo & 3) == 0) {
-        *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
-      } else {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) o[i] = v[i];
-      }
-    }
-    if (a.out_split) {
-      char* base = a.out_split + (((int64_t)orow * (a.cout >> 5) + (col >> 5)) * a.terms) * 64 + (col & 31) * 2;
-      for (int t = 0; t < a.terms; ++t) {
-        bf16x4 q;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          q[i] = (__bf16)v[i];
-          v[i] -= (float)q[i];
-        }
-        *reinterpret_cast<bf16x4*>(base + t * 64) = q;
-      }
-    }
-  }
-}
-
-// Workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8 share an L2).  Map block ids so
-// that each XCD walks a contiguous range of the (spatially sorted) tile schedule: neighbouring tiles
-// gather overlapping input rows, which then hit in that XCD's L2.  Bijective for any tile count.
-__device__ inline int64_t xcd_tile(unsigned bid, unsigned ntiles) {
-  const unsigned xcd = bid & 7u, q = ntiles >> 3, r = ntiles & 7u;
-  const unsigned base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-  return (int64_t)base + (bid >> 3);
-}
-
-// Active kernel offsets of a workgroup (bmask) and of one of its 32-row waves (wmask); with
-// gridDim.z > 1 the offsets are dealt round-robin over z.
-template <int WM>
-__device__ inline void conv_masks(const ConvArgs& a, int64_t tile_base, int wm, uint32_t& bmask,
-                                  uint32_t& wmask) {
-  bmask = 0;
-  wmask = 0;
-  if (a.tile_mask) {
-#pragma unroll
-    for (int w = 0; w < WM; ++w) {
-      const uint32_t m = a.tile_mask[tile_base / 32 + w];
-      bmask |= m;
-      if (w == wm) wmask = m;
-    }
-  } else {
-    bmask = wmask = 1u;
-  }
-  if (gridDim.z > 1) {
-    uint32_t keep = 0;
-    int ord = 0;
-    for (uint32_t m = bmask; m; m &= m - 1, ++ord)
-      if (ord % (int)gridDim.z == (int)blockIdx.z) keep |= m & (0u - m);
-    bmask = keep;
-    wmask &= keep;
-  }
-  bmask = __builtin_amdgcn_readfirstlane(bmask);
-  wmask = __builtin_amdgcn_readfirstlane(wmask);
-}
-
-constexpr int kBK = 32;
-constexpr int kLdr = 36;  // LDS row stride in floats
 
 template <int WM, int WN, int NT>
 __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_f32_kernel(ConvArgs a) {
@@ -541,15 +355,6 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_split_kernel(ConvArgs
 // Pipeline: two LDS buffers; the DMA of stage s+2 is issued right after stage s has been consumed and
 // lands during stage s+1 (counted s_waitcnt vmcnt, raw s_barrier); the kernel map of the tile is
 // staged in LDS once so that no ordinary global load sits between DMAs.
-template <int T>
-struct DmaGeom {
-  static constexpr int SLOTS = T == 2 ? 8 : 16;
-  static constexpr int PIECES = 4 * T;
-  static constexpr int ROWB = SLOTS * 16;
-  __device__ static inline int swz(int r) { return T == 2 ? ((r >> 1) & 7) : (r & 15); }
-};
-
-typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 template <int WM, int WN, int NT, int T, int NBUF>
 __device__ __forceinline__ void conv_igemm_dma_body(const ConvArgs& a) {
@@ -1010,6 +815,9 @@ static ConvPlan plan_conv(int64_t npad, int cout, int kvol, int cin) {
   return p;
 }
 
+int run_conv_halo(const ConvArgs& a, const int32_t* d_cnt, const int32_t* d_rows, const uint16_t* d_loc,
+                  const int32_t* d_order, hipStream_t stream);  // conv_halo.hip
+
 }  // namespace m3d
 
 using namespace m3d;
@@ -1153,7 +961,8 @@ extern "C" int m3d_conv_fwd_sf32(const void* d_in0, int c0, int64_t rows0, const
                                  int64_t rows1, const void* d_weight, int k, int cout,
                                  const int32_t* d_nbr, const int32_t* d_out_row,
                                  const uint32_t* d_tile_mask, int64_t n, int64_t npad,
-                                 const float* d_scale, const float* d_shift, const float* d_residual,
+                                 const int32_t* d_halo_cnt, const int32_t* d_halo_rows, const uint16_t* d_halo_loc,
+                                 const int32_t* d_halo_order, const float* d_scale, const float* d_shift, const float* d_residual,
                                  int relu, float* d_out, int64_t ldo, void* d_out_split, int terms,
                                  void* d_ws, size_t ws_bytes, void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
@@ -1177,6 +986,12 @@ extern "C" int m3d_conv_fwd_sf32(const void* d_in0, int c0, int64_t rows0, const
   a.out = d_out; a.n = n; a.npad = npad; a.ldo = ldo; a.c0 = c0; a.c1 = c1;
   a.cout = cout; a.kvol = k; a.relu = relu;
   a.out_split = static_cast<char*>(d_out_split); a.terms = terms;
+  if (d_halo_cnt != nullptr) {
+    M3D_CHECK_ARG(d_halo_rows && d_halo_loc && d_halo_order && d_nbr, "%s: incomplete halo", who);
+    M3D_CHECK_ARG(terms == 2 && npad % m3d_halo_tile_rows() == 0, "%s: the halo kernel needs terms == 2 and npad %% %d == 0",
+                  who, m3d_halo_tile_rows());
+    return run_conv_halo(a, d_halo_cnt, d_halo_rows, d_halo_loc, d_halo_order, stream);
+  }
   return run_conv(a, terms == 2 ? 3 : 4, true, d_ws, ws_bytes, stream, who);
 }
 

@@ -462,7 +462,7 @@ extern "C" int m3d_strided_rulebook(const int32_t* d_indices, int64_t n, const i
   return M3D_OK;
 }
 
-extern "C" int64_t m3d_schedule_npad(int64_t n) { return cdiv(n > 0 ? n : 1, 128) * 128; }
+extern "C" int64_t m3d_schedule_npad(int64_t n) { return cdiv(n > 0 ? n : 1, 256) * 256; }
 
 extern "C" size_t m3d_schedule_workspace_bytes(int64_t n) {
   if (n <= 0) n = 1;

@@ -69,6 +69,9 @@ class SpUNetEngine:
         # schedule mode of the submanifold maps per level (the last entry repeats): pattern-grouped cells of
         # 64 / 32 voxels per side at the two large levels, one cell where the level fits in L2, voxel order below
         self.sched_modes = [int(m) for m in os.environ.get("M3D_SCHED_MODES", "1539,1283,3843,0").split(",")]
+        # levels whose submanifold convolutions run on the halo kernel (spatially compact Morton tiles)
+        self.halo_levels = [int(m) for m in os.environ.get("M3D_HALO_LEVELS", "").split(",") if m != ""]
+        self.halo_mode = int(os.environ.get("M3D_HALO_MODE", "1"))
         self._terms = {"f32": 0, "bf16x3": 2, "bf16x6": 3}[precision]
         # with a split precision `final` also writes an sf32 copy of the features for the logits GEMM
         self.head_precision = precision
@@ -153,8 +156,11 @@ class SpUNetEngine:
             idx, shape = lv.next_indices, lv.next_shape
         for l, lv in enumerate(levels):
             lv.pair_subm = ops.subm_rulebook(lv.indices, lv.shape)
-            lv.subm = ops.build_schedule(lv.pair_subm, lv.n, lv.indices,
-                                         self.sched_modes[min(l, len(self.sched_modes) - 1)], lv.shape, batch_size)
+            halo = l in self.halo_levels and self._terms == 2
+            mode = self.halo_mode if halo else self.sched_modes[min(l, len(self.sched_modes) - 1)]
+            lv.subm = ops.build_schedule(lv.pair_subm, lv.n, lv.indices, mode, lv.shape, batch_size)
+            if halo:
+                ops.build_halo(lv.subm, lv.n)
             if lv.pair_fwd is not None:
                 lv.down = ops.build_schedule(lv.pair_fwd, lv.n_next, None, 0)
                 lv.up = ops.build_schedule(lv.pair_bwd, lv.n, None, 2, base_order=lv.subm.out_row)

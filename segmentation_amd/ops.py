@@ -175,6 +175,28 @@ class Schedule:
     n: int
     npad: int
     k: int
+    halo: object = None      # optional (cnt [npad/256] i32, rows [npad/256, 640] i32, loc [npad/256, k, 256] i16)
+
+
+def build_halo(sched, n_in, order_by_schedule=True):
+    """Attach the halo of every 256-row tile to a schedule (m3d_build_halo): the distinct input rows the tile's
+    pairs reference and, per pair, its index in that list.  conv_fwd then runs the halo kernel for split (sf32,
+    2-term) inputs.  order_by_schedule=True is for submanifold maps (input rows = output rows)."""
+    lib = _lib.load()
+    dev = sched.nbr.device
+    nt = sched.npad // lib.m3d_halo_tile_rows()
+    assert sched.npad % lib.m3d_halo_tile_rows() == 0
+    cnt = torch.empty((nt,), dtype=torch.int32, device=dev)
+    rows = torch.empty((nt, lib.m3d_halo_cap()), dtype=torch.int32, device=dev)
+    loc = torch.empty((nt, sched.k, lib.m3d_halo_tile_rows()), dtype=torch.int16, device=dev)
+    order = torch.empty((nt,), dtype=torch.int32, device=dev)
+    ws = _workspace(max(int(n_in) * 4, 256), dev)
+    rc = lib.m3d_build_halo(_ptr(sched.nbr), _ptr(sched.out_row), sched.k, sched.npad, int(n_in),
+                            int(bool(order_by_schedule)), _ptr(cnt), _ptr(rows), _ptr(loc), _ptr(order), _ptr(ws),
+                            ws.numel(), _stream())
+    _lib.check(rc, "m3d_build_halo")
+    sched.halo = (cnt, rows, loc, order)
+    return sched
 
 
 def build_schedule(pair, n, indices=None, mode=0, spatial_shape=None, batch_size=1, base_order=None):
@@ -340,10 +362,14 @@ def conv_fwd(in0, weight_packed: PackedWeight, sched: Optional[Schedule], n_out,
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
     osp = None if out_sp is None else out_sp.data
+    hcnt = hrows = hloc = horder = None
+    if sf_in and sched is not None and sched.halo is not None and in0.terms == 2:
+        hcnt, hrows, hloc, horder = sched.halo
     if sf_in:
         rc = lib.m3d_conv_fwd_sf32(_ptr(in0.data), c0, in0.n, _ptr(None if in1 is None else in1.data), c1,
                                    0 if in1 is None else in1.n, _ptr(weight_packed.data), k, cout, _ptr(nbr),
-                                   _ptr(orow), _ptr(mask), n_out, npad, _ptr(scale), _ptr(shift), _ptr(residual),
+                                   _ptr(orow), _ptr(mask), n_out, npad, _ptr(hcnt), _ptr(hrows), _ptr(hloc), _ptr(horder),
+                                   _ptr(scale), _ptr(shift), _ptr(residual),
                                    int(bool(relu)), _ptr(out), ldo, _ptr(osp), in0.terms,
                                    _ptr(ws), ws.numel(), _stream())
         _lib.check(rc, "m3d_conv_fwd_sf32")
@@ -355,7 +381,7 @@ def conv_fwd(in0, weight_packed: PackedWeight, sched: Optional[Schedule], n_out,
         _lib.check(rc, "m3d_conv_fwd_f32")
     if prof is not None:
         ev1.record()
-        kind = ("dma" if sf_in else "igemm") if mfma else "direct"
+        kind = ("halo" if hcnt is not None else "dma" if sf_in else "igemm") if mfma else "direct"
         prof.append((kind, 2.0 * npairs * cin * (flop_cout or cout), ev0, ev1, (n_out, cin, cout, k)))
     return out if not split_terms else (out, out_sp)
 
