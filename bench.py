@@ -142,7 +142,7 @@ def main():
     elapsed, nvox_all = sharding.reduce_job(elapsed, float(nvox), dist, device)
 
     if rank == 0:
-        ig = [(f, e0.elapsed_time(e1) * 1e-3) for kind, f, e0, e1, _ in prof if kind in ("igemm", "dma")]
+        ig = [(f, e0.elapsed_time(e1) * 1e-3) for kind, f, e0, e1, _ in prof if kind in ("igemm", "dma", "halo")]
         flops = sum(f for f, _ in ig)
         secs = sum(t for _, t in ig)
         nl = max(len(ig), 1)
