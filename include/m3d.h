@@ -71,6 +71,39 @@ int m3d_voxelize(const float* d_coord, const float* d_feat, const int64_t* d_off
                  size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * GridSample's deterministic part (mosaic3d/src/data/utils/transform.py:751-762, :813-826, :858-887):
+ * grid = floor(float64(coord) / grid_size) - min, key = FNV64-1A or ravel over (x, y, z), voxels in ascending
+ * key order.  One cloud per call.
+ *   d_grid_coord   [n,3] i32  per-point grid coordinate (after the min shift)
+ *   d_inverse      [n]   i64  voxel of every point (GridSample's `inverse`)
+ *   d_voxel_coords [n,4] i32  (0, x, y, z) of every voxel (GridSample's `grid_coord` of the sampled points)
+ *   d_count        [n]   i32  points per voxel
+ *   d_keys         [n]   u64  sorted unique keys (may be NULL)
+ *   d_meta         [16]  i64  [0]=n_voxels [4..6]=grid min before the shift (min_coord = that * grid_size)
+ * Which point of a voxel is kept (train: random, test: count.max() partitions) is the caller's choice; the
+ * reference's own choice depends on numpy's unstable argsort and its global RNG.
+ */
+size_t m3d_grid_sample_workspace_bytes(int64_t n);
+int m3d_grid_sample(const float* d_coord, int64_t n, double grid_size, int hash_type, int32_t* d_grid_coord,
+                    int64_t* d_inverse, int32_t* d_voxel_coords, int32_t* d_count, uint64_t* d_keys,
+                    int64_t* d_meta, void* d_ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Front end.  m3d_stray_convert replaces the arithmetic of convert_stray.py:24-39: points (float64, Y-up)
+ * -> coord f32 with (x, y, z) -> (x, -z, y); colours in [0, 1] (float64) -> u8 by truncation of c * 255
+ * (d_colors01 / d_color may both be NULL).  m3d_center_shift_normalize replaces CenterShift + NormalizeColor +
+ * Collect(feat_keys=[color]) of transform.py:149-163, :108-113, :23-46: coord - ((xmin+xmax)/2, (ymin+ymax)/2,
+ * zmin or 0) in float32; feat = float32(float64(color) / 127.5 - 1) (d_color / d_feat_out may both be NULL);
+ * d_shift [3] f32 receives the shift.
+ */
+int m3d_stray_convert(const double* d_points, const double* d_colors01, int64_t n, float* d_coord,
+                      uint8_t* d_color, void* stream);
+size_t m3d_center_shift_workspace_bytes(int64_t n);
+int m3d_center_shift_normalize(const float* d_coord, const uint8_t* d_color, int64_t n, int apply_z,
+                               float* d_coord_out, float* d_feat_out, float* d_shift, void* d_ws,
+                               size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Submanifold kernel map (k = 3, dilation 1).  Replaces the indice-pair generation inside
  * spconv.SubMConv3d.forward (call sites spconv_unet_v1m3_pdnorm.py:98-117, :205-212).
  *   d_indices [n,4] i32 (batch, d0, d1, d2), rows distinct

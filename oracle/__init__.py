@@ -10,6 +10,11 @@ Pinning status
 * voxelize (FNV hash, voxel order, v2p_map, spatial shape, offset helpers, ravel key):
   pinned against outputs of the reference's own functions (tests/golden/reference_voxelize.npz,
   produced by tests/golden/make_golden.py from /root/reference).
+* the steps in front of the voxelizer (CenterShift, NormalizeColor, collate offsets, GridSample hash / unique /
+  inverse / grid_coord / min_coord / displacement): pinned against outputs of the reference's own transform
+  classes (tests/golden/reference_preprocess.npz, produced by tests/golden/make_golden_preprocess.py).  The
+  Stray Scanner converter (convert_stray.py) needs open3d, absent here: its three arithmetic lines are restated
+  and checked by known answers only.
 * sparse-conv kernel maps and convolution arithmetic: the reference delegates these to the
   un-vendored third-party wheel ``spconv-cu120`` (version unpinned in
   /root/reference/mosaic3d/requirements.txt:41), which is not installed anywhere and has no
@@ -23,4 +28,5 @@ from .rulebook import subm_rulebook, strided_rulebook, kernel_offsets
 from .sparse_conv import (subm_conv, strided_conv, inverse_conv, conv1x1, dense_equivalent_subm,
                           dense_equivalent_strided)
 from .head import head_logits, head_predict
+from . import preprocess
 from .spunet import spunet_forward, fold_pdnorm, make_spunet_params, SPUNET34C

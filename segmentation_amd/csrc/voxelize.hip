@@ -15,7 +15,11 @@ namespace m3d {
 constexpr uint64_t kFnvOffset = 14695981039346656037ull;
 constexpr uint64_t kFnvPrime = 1099511628211ull;
 
-__device__ inline int grid_of(float x, float gs, float inv_gs, int mode) {
+constexpr int kGridFloor64 = 3;  // GridSample's rule: floor(float64(x) / float64(grid_size)) (transform.py:753-754)
+constexpr int kHashFnv3 = 2;     // FNV64-1A over (x, y, z) only (transform.py:876-887)
+
+__device__ inline int grid_of(float x, float gs, float inv_gs, int mode, double gs64) {
+  if (mode == kGridFloor64) return (int)floor((double)x / gs64);
   float q;
   if (mode == M3D_GRID_RECIP) q = x * inv_gs;
   else q = __fdiv_rn(x, gs);
@@ -45,14 +49,14 @@ __global__ void vox_init_kernel(int* mm) {
 __global__ __launch_bounds__(256) void vox_minmax_kernel(const float* __restrict__ coord,
                                                          const int64_t* __restrict__ offset, int64_t n,
                                                          int b, float gs, float inv_gs, int mode,
-                                                         int* __restrict__ mm) {
+                                                         double gs64, int* __restrict__ mm) {
   int lo[3] = {INT_MAX, INT_MAX, INT_MAX}, hi[3] = {INT_MIN, INT_MIN, INT_MIN};
   int blo = INT_MAX, bhi = INT_MIN;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += (int64_t)gridDim.x * blockDim.x) {
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-      int g = grid_of(coord[i * 3 + a], gs, inv_gs, mode);
+      int g = grid_of(coord[i * 3 + a], gs, inv_gs, mode, gs64);
       lo[a] = min(lo[a], g);
       hi[a] = max(hi[a], g);
     }
@@ -93,7 +97,7 @@ __global__ __launch_bounds__(256) void vox_minmax_kernel(const float* __restrict
 
 __global__ __launch_bounds__(256) void vox_key_kernel(const float* __restrict__ coord,
                                                       const int64_t* __restrict__ offset, int64_t n,
-                                                      int b, float gs, float inv_gs, int mode,
+                                                      int b, float gs, float inv_gs, int mode, double gs64,
                                                       int hash_method, const int* __restrict__ mm,
                                                       uint64_t* __restrict__ keys,
                                                       int4* __restrict__ bc,
@@ -102,7 +106,7 @@ __global__ __launch_bounds__(256) void vox_key_kernel(const float* __restrict__ 
   if (i >= n) return;
   int g[3];
 #pragma unroll
-  for (int a = 0; a < 3; ++a) g[a] = grid_of(coord[i * 3 + a], gs, inv_gs, mode) - mm[a];
+  for (int a = 0; a < 3; ++a) g[a] = grid_of(coord[i * 3 + a], gs, inv_gs, mode, gs64) - mm[a];
   const int bi = batch_of(offset, b, i);
   bc[i] = make_int4(bi, g[0], g[1], g[2]);
   if (grid_out) {
@@ -111,7 +115,12 @@ __global__ __launch_bounds__(256) void vox_key_kernel(const float* __restrict__ 
     grid_out[i * 3 + 2] = g[2];
   }
   uint64_t h;
-  if (hash_method == M3D_HASH_FNV) {
+  if (hash_method == kHashFnv3) {
+    h = kFnvOffset;
+    h *= kFnvPrime; h ^= (uint64_t)(int64_t)g[0];
+    h *= kFnvPrime; h ^= (uint64_t)(int64_t)g[1];
+    h *= kFnvPrime; h ^= (uint64_t)(int64_t)g[2];
+  } else if (hash_method == M3D_HASH_FNV) {
     h = kFnvOffset;
     h *= kFnvPrime; h ^= (uint64_t)(int64_t)bi;
     h *= kFnvPrime; h ^= (uint64_t)(int64_t)g[0];
@@ -204,6 +213,51 @@ extern "C" size_t m3d_voxelize_workspace_bytes(int64_t n, int c) {
   return vox_layout(n, c < 1 ? 1 : c, nullptr, 0, nullptr);
 }
 
+__global__ void copy_counts_kernel(const int32_t* __restrict__ cnt, const int* __restrict__ d_count,
+                                   int32_t* __restrict__ out) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < *d_count) out[r] = cnt[r];
+}
+
+// Shared body of m3d_voxelize (c >= 1 features, float32 grid rule) and m3d_grid_sample (c = 0, float64 rule).
+static int voxelize_impl(const char* who, const float* d_coord, const float* d_feat, const int64_t* d_offset,
+                         int64_t n, int c, int b, float grid_size, double gs64, int pad, int hash_method,
+                         int grid_mode, int32_t* d_voxel_coords, float* d_voxel_feats, int64_t* d_v2p_map,
+                         uint64_t* d_keys, int32_t* d_grid_coord, int32_t* d_count_out, int64_t* d_meta,
+                         void* d_ws, size_t ws_bytes, hipStream_t stream) {
+  VoxWs w;
+  size_t need = vox_layout(n, c < 1 ? 1 : c, d_ws, ws_bytes, &w);
+  if (need > ws_bytes || d_ws == nullptr) {
+    set_error("%s: workspace too small (%zu given, %zu needed)", who, ws_bytes, need);
+    return M3D_ENOSPC;
+  }
+  uint64_t* ukeys = d_keys ? d_keys : w.ukeys;
+  const float inv_gs = 1.0f / grid_size;
+  const int bs = 256;
+  const unsigned gb = (unsigned)cdiv(n, bs);
+  hipLaunchKernelGGL(vox_init_kernel, dim3(1), dim3(64), 0, stream, w.mm);
+  hipLaunchKernelGGL(vox_minmax_kernel, dim3(gb < 512 ? gb : 512), dim3(bs), 0, stream, d_coord,
+                     d_offset, n, b, grid_size, inv_gs, grid_mode, gs64, w.mm);
+  hipLaunchKernelGGL(vox_key_kernel, dim3(gb), dim3(bs), 0, stream, d_coord, d_offset, n, b,
+                     grid_size, inv_gs, grid_mode, gs64, hash_method, w.mm, w.keys, w.bc, d_grid_coord);
+  M3D_LAUNCH_CHECK();
+  int rc = unique_sorted(w.keys, n, 64, ukeys, w.rep, w.inverse, w.count, w.uniq, w.uniq_bytes, stream);
+  if (rc != M3D_OK) return rc;
+  if (c > 0) M3D_HIP(hipMemsetAsync(w.sums, 0, (size_t)n * c * sizeof(double), stream));
+  M3D_HIP(hipMemsetAsync(w.cnt, 0, (size_t)n * sizeof(int32_t), stream));
+  hipLaunchKernelGGL(vox_coords_kernel, dim3(gb), dim3(bs), 0, stream, w.rep, w.bc, w.count,
+                     reinterpret_cast<int4*>(d_voxel_coords));
+  hipLaunchKernelGGL(vox_accum_kernel, dim3(gb), dim3(bs), 0, stream, d_feat, w.inverse, n, c, w.sums,
+                     w.cnt, d_v2p_map);
+  if (c > 0)
+    hipLaunchKernelGGL(vox_mean_kernel, dim3((unsigned)cdiv(n * c, bs)), dim3(bs), 0, stream, w.sums,
+                       w.cnt, w.count, c, d_voxel_feats);
+  if (d_count_out) hipLaunchKernelGGL(copy_counts_kernel, dim3(gb), dim3(bs), 0, stream, w.cnt, w.count, d_count_out);
+  hipLaunchKernelGGL(vox_meta_kernel, dim3(1), dim3(64), 0, stream, w.mm, w.count, pad, d_meta);
+  M3D_LAUNCH_CHECK();
+  return M3D_OK;
+}
+
 extern "C" int m3d_voxelize(const float* d_coord, const float* d_feat, const int64_t* d_offset,
                             int64_t n, int c, int b, float grid_size, int pad, int hash_method,
                             int grid_mode, int32_t* d_voxel_coords, float* d_voxel_feats,
@@ -218,33 +272,26 @@ extern "C" int m3d_voxelize(const float* d_coord, const float* d_feat, const int
   M3D_CHECK_ARG(hash_method == M3D_HASH_FNV || hash_method == M3D_HASH_RAVEL,
                 "m3d_voxelize: unknown hash method %d", hash_method);
   M3D_CHECK_ARG(grid_mode >= 0 && grid_mode <= 2, "m3d_voxelize: unknown grid mode %d", grid_mode);
-  VoxWs w;
-  size_t need = vox_layout(n, c, d_ws, ws_bytes, &w);
-  if (need > ws_bytes || d_ws == nullptr) {
-    set_error("m3d_voxelize: workspace too small (%zu given, %zu needed)", ws_bytes, need);
-    return M3D_ENOSPC;
-  }
-  uint64_t* ukeys = d_keys ? d_keys : w.ukeys;
-  const float inv_gs = 1.0f / grid_size;
-  const int bs = 256;
-  const unsigned gb = (unsigned)cdiv(n, bs);
-  hipLaunchKernelGGL(vox_init_kernel, dim3(1), dim3(64), 0, stream, w.mm);
-  hipLaunchKernelGGL(vox_minmax_kernel, dim3(gb < 512 ? gb : 512), dim3(bs), 0, stream, d_coord,
-                     d_offset, n, b, grid_size, inv_gs, grid_mode, w.mm);
-  hipLaunchKernelGGL(vox_key_kernel, dim3(gb), dim3(bs), 0, stream, d_coord, d_offset, n, b,
-                     grid_size, inv_gs, grid_mode, hash_method, w.mm, w.keys, w.bc, d_grid_coord);
-  M3D_LAUNCH_CHECK();
-  int rc = unique_sorted(w.keys, n, 64, ukeys, w.rep, w.inverse, w.count, w.uniq, w.uniq_bytes, stream);
-  if (rc != M3D_OK) return rc;
-  M3D_HIP(hipMemsetAsync(w.sums, 0, (size_t)n * c * sizeof(double), stream));
-  M3D_HIP(hipMemsetAsync(w.cnt, 0, (size_t)n * sizeof(int32_t), stream));
-  hipLaunchKernelGGL(vox_coords_kernel, dim3(gb), dim3(bs), 0, stream, w.rep, w.bc, w.count,
-                     reinterpret_cast<int4*>(d_voxel_coords));
-  hipLaunchKernelGGL(vox_accum_kernel, dim3(gb), dim3(bs), 0, stream, d_feat, w.inverse, n, c, w.sums,
-                     w.cnt, d_v2p_map);
-  hipLaunchKernelGGL(vox_mean_kernel, dim3((unsigned)cdiv(n * c, bs)), dim3(bs), 0, stream, w.sums,
-                     w.cnt, w.count, c, d_voxel_feats);
-  hipLaunchKernelGGL(vox_meta_kernel, dim3(1), dim3(64), 0, stream, w.mm, w.count, pad, d_meta);
-  M3D_LAUNCH_CHECK();
-  return M3D_OK;
+  return voxelize_impl("m3d_voxelize", d_coord, d_feat, d_offset, n, c, b, grid_size, (double)grid_size, pad,
+                       hash_method, grid_mode, d_voxel_coords, d_voxel_feats, d_v2p_map, d_keys, d_grid_coord,
+                       nullptr, d_meta, d_ws, ws_bytes, stream);
+}
+
+extern "C" size_t m3d_grid_sample_workspace_bytes(int64_t n) { return vox_layout(n, 1, nullptr, 0, nullptr); }
+
+extern "C" int m3d_grid_sample(const float* d_coord, int64_t n, double grid_size, int hash_type,
+                               int32_t* d_grid_coord, int64_t* d_inverse, int32_t* d_voxel_coords,
+                               int32_t* d_count, uint64_t* d_keys, int64_t* d_meta, void* d_ws,
+                               size_t ws_bytes, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  M3D_CHECK_ARG(n > 0 && n < (int64_t)INT_MAX, "m3d_grid_sample: n=%lld out of range", (long long)n);
+  M3D_CHECK_ARG(d_coord && d_grid_coord && d_inverse && d_voxel_coords && d_count && d_meta,
+                "m3d_grid_sample: null pointer");
+  M3D_CHECK_ARG(grid_size > 0.0, "m3d_grid_sample: grid_size must be positive");
+  M3D_CHECK_ARG(hash_type == M3D_HASH_FNV || hash_type == M3D_HASH_RAVEL, "m3d_grid_sample: unknown hash type %d",
+                hash_type);
+  // one cloud: batch index 0 everywhere (the offset array is never read when b == 1)
+  return voxelize_impl("m3d_grid_sample", d_coord, nullptr, nullptr, n, 0, 1, (float)grid_size, grid_size, 0,
+                       hash_type == M3D_HASH_FNV ? kHashFnv3 : M3D_HASH_RAVEL, kGridFloor64, d_voxel_coords, nullptr,
+                       d_inverse, d_keys, d_grid_coord, d_count, d_meta, d_ws, ws_bytes, stream);
 }
