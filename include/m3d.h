@@ -103,6 +103,23 @@ int m3d_center_shift_normalize(const float* d_coord, const uint8_t* d_color, int
                                float* d_coord_out, float* d_feat_out, float* d_shift, void* d_ws,
                                size_t ws_bytes, void* stream);
 
+/* Depth back-projection of one Stray Scanner frame, fused with the converter's Y-up -> Z-up rotation
+ * (convert_stray.py:24-29 gives the output contract: f32 coordinates (x, -z, y), u8 colours; the reference
+ * itself has no back-projection, it starts from a cloud made elsewhere).
+ *   d_depth [h,w] u16 raw units (0 = no reading), d_conf [h,w] u8 or NULL, d_rgb [hc,wc,3] u8 or NULL
+ *   intrinsics = (fx, fy, cx, cy) at depth resolution; pose_c2w = row-major 4x4 camera-to-world
+ *   (camera axes: x right, y down, z forward); a pixel is kept iff depth != 0, conf >= conf_min and
+ *   depth * depth_scale <= depth_max; every stride-th pixel of every stride-th row is visited.
+ *   p_cam = ((u - cx) / fx * d, (v - cy) / fy * d, d) in float64, p_world = R p_cam + t.
+ * Output: the kept pixels in row-major order are appended at d_coord[*d_count ...] (and d_color), *d_count
+ * (device, i64) is advanced; a frame that would exceed `capacity` rows is dropped as a whole.
+ */
+size_t m3d_backproject_workspace_bytes(int h, int w, int stride);
+int m3d_backproject(const uint16_t* d_depth, const uint8_t* d_conf, const uint8_t* d_rgb, int h, int w, int hc,
+                    int wc, const double intrinsics[4], const double pose_c2w[16], double depth_scale,
+                    double depth_max, int conf_min, int stride, float* d_coord, uint8_t* d_color,
+                    int64_t capacity, int64_t* d_count, void* d_ws, size_t ws_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Submanifold kernel map (k = 3, dilation 1).  Replaces the indice-pair generation inside
  * spconv.SubMConv3d.forward (call sites spconv_unet_v1m3_pdnorm.py:98-117, :205-212).

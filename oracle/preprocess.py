@@ -113,3 +113,33 @@ def grid_sample_test_parts(inverse, count):
     idx_sort = np.argsort(inverse, kind="stable")
     start = np.cumsum(np.insert(count, 0, 0)[0:-1])
     return [idx_sort[start + i % count] for i in range(int(count.max()))]
+
+
+def backproject(depth_u16, intrinsics, pose_c2w, conf=None, rgb=None, depth_scale=1e-3, depth_max=5.0, conf_min=2,
+                stride=1):
+    """Pinhole back-projection of one depth frame followed by the converter's rotation (convert_stray.py:24-29).
+    The reference has no back-projection of its own (it starts from a cloud made elsewhere): parity unpinned,
+    this is the definition the GPU kernel is held to.  Camera axes x right, y down, z forward; float64 maths;
+    kept pixels in row-major order."""
+    depth = np.asarray(depth_u16)[::stride, ::stride]
+    h, w = np.asarray(depth_u16).shape
+    v, u = np.meshgrid(np.arange(0, h, stride), np.arange(0, w, stride), indexing="ij")
+    keep = depth != 0
+    if conf is not None:
+        keep &= np.asarray(conf)[::stride, ::stride] >= conf_min
+    d = depth.astype(np.float64) * depth_scale
+    keep &= d <= depth_max
+    fx, fy, cx, cy = [float(x) for x in intrinsics]
+    pose = np.asarray(pose_c2w, dtype=np.float64).reshape(4, 4)
+    u, v, d = u[keep].astype(np.float64), v[keep].astype(np.float64), d[keep]
+    xc, yc, zc = (u - cx) / fx * d, (v - cy) / fy * d, d
+    world = [pose[r, 0] * xc + pose[r, 1] * yc + pose[r, 2] * zc + pose[r, 3] for r in range(3)]
+    coord = np.stack([world[0], -world[2], world[1]], 1).astype(np.float32)
+    color = None
+    if rgb is not None:
+        rgb = np.asarray(rgb)
+        hc, wc = rgb.shape[:2]
+        uc = np.minimum((u.astype(np.int64) * wc) // w, wc - 1)
+        vc = np.minimum((v.astype(np.int64) * hc) // h, hc - 1)
+        color = rgb[vc, uc]
+    return coord, color

@@ -26,6 +26,10 @@ SIGNATURES = {
     "m3d_stray_convert": (_int, [_vp, _vp, _i64, _vp, _vp, _vp]),
     "m3d_center_shift_workspace_bytes": (_sz, [_i64]),
     "m3d_center_shift_normalize": (_int, [_vp, _vp, _i64, _int, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "m3d_backproject_workspace_bytes": (_sz, [_int, _int, _int]),
+    "m3d_backproject": (_int, [_vp, _vp, _vp, _int, _int, _int, _int, ctypes.POINTER(ctypes.c_double),
+                               ctypes.POINTER(ctypes.c_double), ctypes.c_double, ctypes.c_double, _int, _int, _vp, _vp,
+                               _i64, _vp, _vp, _sz, _vp]),
     "m3d_subm_rulebook_workspace_bytes": (_sz, [_i64]),
     "m3d_subm_rulebook": (_int, [_vp, _i64, ctypes.POINTER(_i64), _vp, _vp, _sz, _vp]),
     "m3d_strided_rulebook_workspace_bytes": (_sz, [_i64, ctypes.POINTER(_i64), _int]),

@@ -30,6 +30,49 @@ def stray_convert(points: torch.Tensor, colors01: torch.Tensor = None):
     return coord, color
 
 
+class Backprojector:
+    """Accumulates the world points of Stray Scanner frames on the GPU (m3d_backproject): `add_frame` appends the
+    valid pixels of one depth frame (already rotated to Mosaic3D's Z-up axes), `result()` returns coord [M,3] f32
+    and color [M,3] u8, ready for `val_sample`.  The running count stays on the device; frames are enqueued
+    without host read-backs."""
+
+    def __init__(self, capacity: int, device="cuda", with_color: bool = True):
+        self.capacity = int(capacity)
+        self.coord = torch.empty((self.capacity, 3), dtype=torch.float32, device=device)
+        self.color = torch.empty((self.capacity, 3), dtype=torch.uint8, device=device) if with_color else None
+        self.count = torch.zeros((1,), dtype=torch.int64, device=device)
+
+    def add_frame(self, depth_u16: torch.Tensor, intrinsics, pose_c2w, conf: torch.Tensor = None, rgb: torch.Tensor = None,
+                  depth_scale: float = 1e-3, depth_max: float = 5.0, conf_min: int = 2, stride: int = 1):
+        import ctypes
+        lib = _lib.load()
+        _need_cuda(depth_u16)
+        h, w = depth_u16.shape
+        depth_u16 = depth_u16.contiguous()
+        assert depth_u16.dtype in (torch.uint16, torch.int16)
+        if conf is not None:
+            conf = conf.contiguous()
+            assert conf.dtype == torch.uint8 and conf.shape == (h, w)
+        hc = wc = 0
+        if self.color is not None:
+            assert rgb is not None and rgb.dtype == torch.uint8 and rgb.dim() == 3 and rgb.shape[2] == 3
+            rgb = rgb.contiguous()
+            hc, wc = rgb.shape[:2]
+        else:
+            rgb = None
+        k = (ctypes.c_double * 4)(*[float(x) for x in intrinsics])
+        p = (ctypes.c_double * 16)(*[float(x) for x in torch.as_tensor(pose_c2w, dtype=torch.float64).flatten().tolist()])
+        ws = _workspace(lib.m3d_backproject_workspace_bytes(h, w, int(stride)), depth_u16.device)
+        rc = lib.m3d_backproject(_ptr(depth_u16), _ptr(conf), _ptr(rgb), h, w, hc, wc, k, p, float(depth_scale),
+                                 float(depth_max), int(conf_min), int(stride), _ptr(self.coord), _ptr(self.color),
+                                 self.capacity, _ptr(self.count), _ptr(ws), ws.numel(), _stream())
+        _lib.check(rc, "m3d_backproject")
+
+    def result(self):
+        m = int(self.count.item())
+        return self.coord[:m], (None if self.color is None else self.color[:m])
+
+
 def center_shift_normalize(coord: torch.Tensor, color_u8: torch.Tensor = None, apply_z: bool = True):
     """CenterShift(apply_z) + NormalizeColor + `.float()`: returns (coord - shift, feat or None, shift [3])."""
     lib = _lib.load()

@@ -80,3 +80,51 @@ def test_stray_convert(device):
     assert np.array_equal(coord.cpu().numpy(), rc) and np.array_equal(color.cpu().numpy(), rcol)
     only, none = pp.stray_convert(torch.from_numpy(pts).to(device))
     assert none is None and np.array_equal(only.cpu().numpy(), rc)
+
+
+def _frame(rng, h=192, w=256, hc=1440, wc=1920):
+    depth = rng.integers(300, 6000, size=(h, w)).astype(np.uint16)
+    depth[rng.uniform(size=(h, w)) < 0.1] = 0
+    conf = rng.integers(0, 3, size=(h, w)).astype(np.uint8)
+    rgb = rng.integers(0, 256, size=(hc, wc, 3)).astype(np.uint8)
+    ang = rng.uniform(-1, 1, size=3)
+    cx, sx, cy, sy, cz, sz = np.cos(ang[0]), np.sin(ang[0]), np.cos(ang[1]), np.sin(ang[1]), np.cos(ang[2]), np.sin(ang[2])
+    rot = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]]) @ np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]]) @ \
+        np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]])
+    pose = np.eye(4)
+    pose[:3, :3] = rot
+    pose[:3, 3] = rng.uniform(-2, 2, size=3)
+    intr = (212.3, 211.9, w / 2 - 0.7, h / 2 + 0.4)
+    return depth, conf, rgb, intr, pose
+
+
+@pytest.mark.parametrize("stride", [1, 2])
+def test_backproject_frames_accumulate_in_pixel_order(device, stride):
+    # no back-projection exists in the reference: the oracle's pinhole definition is the bar (parity unpinned)
+    rng = np.random.default_rng(5)
+    frames = [_frame(rng) for _ in range(3)]
+    bp = pp.Backprojector(capacity=3 * 192 * 256, device=device)
+    ref_c, ref_k = [], []
+    for depth, conf, rgb, intr, pose in frames:
+        bp.add_frame(torch.from_numpy(depth.view(np.int16)).to(device), intr, pose, conf=torch.from_numpy(conf).to(device), rgb=torch.from_numpy(rgb).to(device), stride=stride)
+        c, k = P.backproject(depth, intr, pose, conf=conf, rgb=rgb, stride=stride)
+        ref_c.append(c)
+        ref_k.append(k)
+    coord, color = bp.result()
+    ref_c, ref_k = np.concatenate(ref_c), np.concatenate(ref_k)
+    assert coord.shape[0] == ref_c.shape[0] > 5000
+    assert np.array_equal(color.cpu().numpy(), ref_k)
+    # float64 maths on both sides; fma contraction on the GPU may differ in the last float32 bit
+    assert np.abs(coord.cpu().numpy() - ref_c).max() <= 1e-6 * np.abs(ref_c).max()
+
+
+def test_backproject_drops_a_frame_that_does_not_fit(device):
+    rng = np.random.default_rng(6)
+    depth, conf, rgb, intr, pose = _frame(rng)
+    n_valid = P.backproject(depth, intr, pose, conf=conf)[0].shape[0]
+    bp = pp.Backprojector(capacity=n_valid + 10, device=device, with_color=False)
+    d = torch.from_numpy(depth.view(np.int16)).to(device)
+    bp.add_frame(d, intr, pose, conf=torch.from_numpy(conf).to(device))
+    bp.add_frame(d, intr, pose, conf=torch.from_numpy(conf).to(device))
+    coord, color = bp.result()
+    assert coord.shape[0] == n_valid and color is None
