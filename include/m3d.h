@@ -221,6 +221,27 @@ int m3d_conv_fwd_sf32(const void* d_in0, int c0, int64_t rows0, const void* d_in
                       float* d_out, int64_t ldo, void* d_out_split, int terms, void* d_ws,
                       size_t ws_bytes, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Training step (the backward of SubMConv3d / SparseConv3d / SparseInverseConv3d / the 1x1 convolution that
+ * spconv computes for train_spunet_multidata_ppt, mosaic3d/src/models/lightning_modules/language_module.py:209-277).
+ *
+ * Input gradient: no entry point of its own.  With pair[k][j] = i the forward map,
+ *   din[i] = sum_k W[k]^T dout[j]  over the (k, j) with pair[k][j] = i,
+ * which is the FORWARD convolution (m3d_conv_fwd_f32) of dout with the transposed weights
+ *   - submanifold k = 3: over the same schedule, weights W'[k] = W[26 - k]^T (pair[26-k][i] = j <=> pair[k][j] = i);
+ *   - strided k2 s2: over the schedule of pair_bwd, weights W[k]^T;  its inverse: over the schedule of pair_fwd;
+ *   - 1x1: dense, weights W^T.
+ *
+ * Weight gradient:  dW[co][k][ci] = sum_t dout[out_row[t]][co] * in[nbr[k][t]][ci], exact f32
+ * (v_mfma_f32_32x32x2_f32), deterministic.  cin and cout must be multiples of 32 (pad the 3-channel stem input
+ * with zero channels).  d_dweight has the reference layout [cout, k, cin].
+ */
+size_t m3d_conv_bwd_weight_workspace_bytes(int64_t n, int cin, int cout, int k);
+int m3d_conv_bwd_weight_f32(const float* d_in, int cin, const float* d_dout, int cout, int k,
+                            const int32_t* d_nbr, const int32_t* d_out_row, const uint32_t* d_tile_mask,
+                            int64_t n, int64_t npad, float* d_dweight, void* d_ws, size_t ws_bytes,
+                            void* stream);
+
 /* Halo of a tile schedule (optional accelerator of m3d_conv_fwd_sf32 with terms = 2, meant for 3x3x3
  * submanifold maps of large levels).  For every tile of m3d_halo_tile_rows() = 256 schedule rows: the
  * distinct input rows its pairs reference (at most m3d_halo_cap() = 640; a tile with more is marked -1

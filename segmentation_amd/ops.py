@@ -387,6 +387,39 @@ def conv_fwd(in0, weight_packed: PackedWeight, sched: Optional[Schedule], n_out,
 
 
 # ----------------------------------------------------------------------------- head
+def conv_bwd_weight(x, dout, sched, k):
+    """Weight gradient of a sparse convolution (m3d_conv_bwd_weight_f32): x [n_in, Cin] f32 the layer's input,
+    dout [n_out, Cout] f32 the gradient of its output, sched the schedule the forward ran on (None = dense 1x1).
+    Returns dW [Cout, k, Cin] f32.  Channel counts that are not multiples of 32 (the 3-channel stem) are
+    zero-padded for the kernel and the padding is dropped from the result."""
+    lib = _lib.load()
+    _need_cuda(x, dout)
+    n, cout = dout.shape
+    cin = x.shape[1]
+    pin, pout = (-cin) % 32, (-cout) % 32
+    xk = torch.nn.functional.pad(x.float(), (0, pin)).contiguous() if pin else x.float().contiguous()
+    dk = torch.nn.functional.pad(dout.float(), (0, pout)).contiguous() if pout else dout.float().contiguous()
+    ci, co = cin + pin, cout + pout
+    dev = x.device
+    dw = torch.empty((co, k, ci), dtype=torch.float32, device=dev)
+    if n == 0:
+        return dw.zero_()[:cout, :, :cin]
+    if sched is None:
+        if k != 1:
+            raise ValueError("a convolution without a schedule must have one kernel offset")
+        nbr = orow = mask = None
+        npad = lib.m3d_schedule_npad(n)
+    else:
+        if sched.k != k or sched.n != n:
+            raise ValueError("schedule does not match the output gradient")
+        nbr, orow, mask, npad = sched.nbr, sched.out_row, sched.tile_mask, sched.npad
+    ws = _workspace(lib.m3d_conv_bwd_weight_workspace_bytes(n, ci, co, k), dev)
+    rc = lib.m3d_conv_bwd_weight_f32(_ptr(xk), ci, _ptr(dk), co, k, _ptr(nbr), _ptr(orow), _ptr(mask), n, npad,
+                                     _ptr(dw), _ptr(ws), ws.numel(), _stream())
+    _lib.check(rc, "m3d_conv_bwd_weight_f32")
+    return dw[:cout, :, :cin] if (pin or pout) else dw
+
+
 def argmax_rows(logits, n_classes):
     lib = _lib.load()
     _need_cuda(logits)

@@ -245,11 +245,11 @@ class SparseConvolution(SparseModule):
         if not isinstance(x, SparseConvTensor):
             raise TypeError(f"expected SparseConvTensor, got {type(x).__name__}")
         feats = x.features
-        if torch.is_grad_enabled() and (feats.requires_grad or self.weight.requires_grad):
-            raise RuntimeError("segmentation_amd sparse convolutions are forward-only in this build: "
-                               "call the model under torch.no_grad() / torch.inference_mode()")
         if feats.shape[1] != self.in_channels:
             raise ValueError(f"expected {self.in_channels} input channels, got {feats.shape[1]}")
+        if torch.is_grad_enabled() and (feats.requires_grad or self.weight.requires_grad
+                                        or (self.bias is not None and self.bias.requires_grad)):
+            return self._forward_train(x)
         in_dtype = feats.dtype
         feats = feats.float().contiguous()
         w = self.packed_weight()
@@ -268,6 +268,59 @@ class SparseConvolution(SparseModule):
             res = SparseConvTensor(out.to(in_dtype), data.out_indices, data.out_spatial_shape, x.batch_size,
                                    x.grid, x.voxel_num, x.indice_dict, x.benchmark)
         return res
+
+
+    def _forward_train(self, x: SparseConvTensor):
+        """Differentiable path (exact f32): the same kernels under a torch.autograd.Function."""
+        feats = x.features.float()
+        if self.conv1x1:
+            out = _SparseConvFn.apply(feats, self.weight, self.bias, None, None, feats.shape[0], feats.shape[0], False)
+            return x.replace_feature(out)
+        data = self._get_indice_data(x)
+        if self.inverse:
+            n_out, n_in = data.indices.shape[0], data.out_indices.shape[0]
+            out = _SparseConvFn.apply(feats, self.weight, self.bias, data.sched_bwd, data.sched_fwd, n_out, n_in, False)
+            return SparseConvTensor(out, data.indices, data.spatial_shape, x.batch_size, x.grid, x.voxel_num,
+                                    x.indice_dict, x.benchmark)
+        n_out, n_in = data.out_indices.shape[0], data.indices.shape[0]
+        back = data.sched_fwd if data.is_subm else data.sched_bwd
+        out = _SparseConvFn.apply(feats, self.weight, self.bias, data.sched_fwd, back, n_out, n_in, data.is_subm)
+        return SparseConvTensor(out, data.out_indices, data.out_spatial_shape, x.batch_size, x.grid, x.voxel_num,
+                                x.indice_dict, x.benchmark)
+
+
+class _SparseConvFn(torch.autograd.Function):
+    """out = conv(feats, weight) + bias through m3d_conv_fwd_f32; the input gradient is the forward kernel on the
+    transposed weights over the transposed kernel map (for a submanifold map: the same schedule with the kernel
+    offsets reversed), the weight gradient is m3d_conv_bwd_weight_f32."""
+
+    @staticmethod
+    def forward(ctx, feats, weight, bias, sched_fwd, sched_back, n_out, n_in, flip):
+        feats = feats.contiguous()
+        w = ops.pack_weight(weight.detach(), "f32")
+        out = ops.conv_fwd(feats, w, sched_fwd, n_out, shift=None if bias is None else bias.detach().float().contiguous())
+        ctx.save_for_backward(feats, weight)
+        ctx.meta = (sched_fwd, sched_back, n_out, n_in, flip, bias is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        feats, weight = ctx.saved_tensors
+        sched_fwd, sched_back, n_out, n_in, flip, has_bias = ctx.meta
+        dout = dout.contiguous().float()
+        cout, cin = weight.shape[0], weight.shape[-1]
+        k = weight.numel() // (cout * cin)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            wt = weight.detach().reshape(cout, k, cin).permute(2, 1, 0)  # [Cin, k, Cout]
+            if flip:
+                wt = wt.flip(1)
+            dx = ops.conv_fwd(dout, ops.pack_weight(wt.contiguous(), "f32"), sched_back, n_in)
+        if ctx.needs_input_grad[1]:
+            dw = ops.conv_bwd_weight(feats, dout, sched_fwd, k).reshape(weight.shape)
+        if has_bias and ctx.needs_input_grad[2]:
+            db = dout.sum(0)
+        return dx, dw, db, None, None, None, None, None
 
 
 class SubMConv3d(SparseConvolution):

@@ -1,0 +1,131 @@
+"""Training step of train_spunet_multidata_ppt on the HIP kernels.
+
+Mirrors DenseLanguageLitModule.training_step (mosaic3d/src/models/lightning_modules/language_module.py:209-277),
+CaptionLoss.loss and CaptionLossBase.extract_text_features (mosaic3d/src/models/losses/caption_loss.py:195-235,
+:25-49), the optimiser / scheduler of configs/optim/sgd.yaml:2-8 and configs/scheduler/onecyclelr.yaml:2-11 and the
+data-parallel gradient exchange of configs/trainer/ddp.yaml (one process per GPU, `torch.distributed` over RCCL,
+local batch-norm statistics).  The sparse convolutions run forward and backward on the kernels of the C ABI
+(sparse._SparseConvFn); normalisation, activation and the loss are torch ops on the same device.
+"""
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from .sparse import segment_csr
+
+
+def unique_text_features(embeddings: Sequence[Sequence[torch.Tensor]]):
+    """extract_text_features with precomputed embeddings (caption_loss.py:30-39): unique rows of the stacked
+    caption embeddings (np.unique along axis 0) -> (text_features [U,D], labels_per_segment [S], labels_per_caption [U])."""
+    text = torch.stack([item for sub in embeddings for item in sub], 0)
+    device = text.device
+    _, first, inverse = np.unique(text.detach().cpu().numpy(), return_index=True, return_inverse=True, axis=0)
+    first = torch.from_numpy(first).to(device)
+    return text[first], torch.from_numpy(np.asarray(inverse).reshape(-1)).to(device), first
+
+
+def caption_loss(point_features, text_features, labels_per_segment, point_indices, caption_offsets,
+                 num_points_per_caption, normalize: bool = True, logit_scale: Optional[torch.Tensor] = None,
+                 reduction: str = "weighted_sum"):
+    """CaptionLoss.loss after the text features are known (caption_loss.py:212-235)."""
+    device = point_features.device
+    if normalize:
+        point_features = F.normalize(point_features, dim=-1)
+    logits = point_features @ text_features.T.to(device)
+    if logit_scale is not None:
+        logits = logit_scale.exp() * logits
+    scores = F.log_softmax(logits, dim=-1)
+    rep = scores[point_indices]
+    reduced = segment_csr(rep, caption_offsets.to(device), reduce="mean")
+    loss = F.nll_loss(reduced, labels_per_segment.to(device), reduction="none")
+    if reduction == "mean":
+        return loss.mean()
+    if reduction == "weighted_sum":
+        w = num_points_per_caption.to(loss.device)
+        return (loss * w).sum() / w.sum()
+    raise ValueError(f"unknown reduction {reduction!r}")
+
+
+def flatten_caption_indices(batched_indices: Sequence[Sequence[torch.Tensor]], batch_offsets: torch.Tensor):
+    """convert_list_list_tensor_to_tensor (mosaic3d/src/data/utils/collate.py:32-70 call site :123-130): per-scene lists of
+    per-caption point index tensors -> (point_indices [L] shifted by the scene's first point, caption_offsets [S+1],
+    num_points_per_caption [S])."""
+    idx, counts = [], []
+    for b, scene in enumerate(batched_indices):
+        for t in scene:
+            idx.append(t.long() + int(batch_offsets[b]))
+            counts.append(t.numel())
+    counts = torch.tensor(counts, dtype=torch.int64)
+    offsets = torch.cat([torch.zeros(1, dtype=torch.int64), torch.cumsum(counts, 0)])
+    return torch.cat(idx), offsets, counts
+
+
+def allreduce_gradients(params, dist=None, bucket_bytes: int = 64 << 20):
+    """Average the gradients over the data-parallel ranks: parameters are packed into flat buckets (64 MB by
+    default: few, large ring all-reduces suit the point-to-point xGMI links) and all-reduced; no-op without a
+    process group."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return 0
+    world = dist.get_world_size()
+    grads = [p.grad for p in params if p.grad is not None]
+    buckets, cur, size = [], [], 0
+    for g in grads:
+        cur.append(g)
+        size += g.numel() * g.element_size()
+        if size >= bucket_bytes:
+            buckets.append(cur)
+            cur, size = [], 0
+    if cur:
+        buckets.append(cur)
+    for b in buckets:
+        flat = torch.cat([g.reshape(-1) for g in b])
+        dist.all_reduce(flat)
+        flat /= world
+        o = 0
+        for g in b:
+            g.copy_(flat[o:o + g.numel()].view_as(g))
+            o += g.numel()
+    return len(buckets)
+
+
+class TrainStep:
+    """One optimisation step: forward (kernel maps + SpUNet in train mode), caption loss, backward, gradient
+    all-reduce, SGD(nesterov) + OneCycleLR."""
+
+    def __init__(self, model: torch.nn.Module, total_steps: int, lr: float = 5e-2, momentum: float = 0.9,
+                 weight_decay: float = 1e-4, pct_start: float = 0.05, div_factor: float = 10.0,
+                 final_div_factor: float = 1000.0, dist=None, use_logit_scale: bool = False):
+        self.model = model
+        self.dist = dist
+        self.logit_scale = None
+        params = list(model.parameters())
+        if use_logit_scale:
+            self.logit_scale = torch.nn.Parameter(torch.ones([], device=params[0].device) * float(np.log(1 / 0.07)))
+            params.append(self.logit_scale)
+        self.params = params
+        self.opt = torch.optim.SGD(params, lr=lr, momentum=momentum, weight_decay=weight_decay, nesterov=True)
+        self.sched = torch.optim.lr_scheduler.OneCycleLR(self.opt, max_lr=lr, total_steps=total_steps, pct_start=pct_start,
+                                                         anneal_strategy="cos", div_factor=div_factor,
+                                                         final_div_factor=final_div_factor)
+
+    def loss(self, batch: Dict):
+        out = self.model(batch)
+        feats = out["sparse_conv_feat"].features if isinstance(out, dict) else out.sparse_conv_feat.features
+        v2p = out["v2p_map"] if isinstance(out, dict) else out.v2p_map
+        clip_feat = feats[v2p]  # language_module.py:205
+        cd = batch["caption_data"]
+        text, seg_labels, _ = unique_text_features(cd["embedding"])
+        return caption_loss(clip_feat, text, seg_labels, cd["point_indices"], cd["caption_offsets"],
+                            cd["num_points_per_caption"], logit_scale=self.logit_scale)
+
+    def __call__(self, batch: Dict) -> float:
+        self.model.train()
+        self.opt.zero_grad(set_to_none=True)
+        loss = self.loss(batch)
+        loss.backward()
+        allreduce_gradients(self.params, self.dist)
+        self.opt.step()
+        self.sched.step()
+        return float(loss.detach())

@@ -1,0 +1,212 @@
+"""Training path on the GPU: the backward of every sparse convolution type against torch autograd on the CPU
+oracle (float64), the caption loss, and one whole optimisation step of a small PPT/SpUNet against the same
+network evaluated on the CPU with the oracle's convolutions.  Tolerances: single layers 1e-5 relative L2 (exact
+f32 products), whole-network gradients 2e-3 per parameter (float32 batch-norm statistics through 30+ layers)."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from segmentation_amd import ops, scenes, sparse, spunet, train
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    b = b.double()
+    return ((a.double().cpu() - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+@pytest.fixture(scope="module")
+def level():
+    sc = scenes.make_scene(seed=11, target_voxels=5000)
+    off = np.array([0, sc["coord"].shape[0]], dtype=np.int64)
+    sp = oracle.sparsify(sc["coord"], sc["feat"], off, 0.02)
+    pair = oracle.subm_rulebook(sp["voxel_coords"], sp["spatial_shape"])
+    oi, oshape, pf, pb = oracle.strided_rulebook(sp["voxel_coords"], sp["spatial_shape"])
+    return dict(sp=sp, pair=pair, oi=oi, oshape=oshape, pf=pf, pb=pb)
+
+
+def _tensor(device, level, feats):
+    sp = level["sp"]
+    return sparse.SparseConvTensor(feats, torch.from_numpy(sp["voxel_coords"]).to(device), sp["spatial_shape"], 1)
+
+
+@pytest.mark.parametrize("cin,cout,bias", [(3, 32, False), (32, 64, True), (96, 96, False), (192, 128, False)])
+def test_subm_conv_backward(device, level, cin, cout, bias):
+    g = torch.Generator().manual_seed(cin + cout)
+    n = level["sp"]["voxel_coords"].shape[0]
+    x = torch.randn(n, cin, generator=g)
+    conv = sparse.SubMConv3d(cin, cout, 3, bias=bias, indice_key="k").to(device)
+    xg = x.to(device).requires_grad_(True)
+    out = conv(_tensor(device, level, xg)).features
+    gout = torch.randn(n, cout, generator=g)
+    out.backward(gout.to(device))
+    xr = x.double().requires_grad_(True)
+    wr = conv.weight.detach().cpu().double().requires_grad_(True)
+    br = None if not bias else conv.bias.detach().cpu().double().requires_grad_(True)
+    ref = oracle.subm_conv(xr, wr, level["pair"], br)
+    ref.backward(gout.double())
+    assert _rel(out.detach(), ref.detach()) < 1e-5
+    assert _rel(xg.grad, xr.grad) < 1e-5
+    assert _rel(conv.weight.grad, wr.grad) < 1e-5
+    if bias:
+        assert _rel(conv.bias.grad, br.grad) < 1e-5
+
+
+def test_strided_and_inverse_conv_backward(device, level):
+    g = torch.Generator().manual_seed(3)
+    n, m = level["sp"]["voxel_coords"].shape[0], level["oi"].shape[0]
+    x = torch.randn(n, 32, generator=g)
+    down = sparse.SparseConv3d(32, 64, 2, stride=2, bias=False, indice_key="s").to(device)
+    up = sparse.SparseInverseConv3d(64, 32, 2, indice_key="s", bias=False).to(device)
+    xg = x.to(device).requires_grad_(True)
+    mid = down(_tensor(device, level, xg))
+    assert mid.features.shape[0] == m
+    out = up(mid).features
+    gout = torch.randn(n, 32, generator=g)
+    out.backward(gout.to(device))
+    xr = x.double().requires_grad_(True)
+    wd = down.weight.detach().cpu().double().requires_grad_(True)
+    wu = up.weight.detach().cpu().double().requires_grad_(True)
+    ref = oracle.inverse_conv(oracle.strided_conv(xr, wd, level["pf"]), wu, level["pb"])
+    ref.backward(gout.double())
+    assert _rel(out.detach(), ref.detach()) < 1e-5
+    assert _rel(xg.grad, xr.grad) < 1e-5
+    assert _rel(down.weight.grad, wd.grad) < 1e-5
+    assert _rel(up.weight.grad, wu.grad) < 1e-5
+
+
+def test_conv1x1_backward(device):
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(3000, 96, generator=g)
+    conv = sparse.SubMConv3d(96, 768, 1, bias=True).to(device)
+    idx = torch.zeros((3000, 4), dtype=torch.int32, device=device)
+    xg = x.to(device).requires_grad_(True)
+    out = conv(sparse.SparseConvTensor(xg, idx, [8, 8, 8], 1)).features
+    gout = torch.randn(3000, 768, generator=g)
+    out.backward(gout.to(device))
+    xr = x.double().requires_grad_(True)
+    wr = conv.weight.detach().cpu().double().requires_grad_(True)
+    br = conv.bias.detach().cpu().double().requires_grad_(True)
+    ref = oracle.conv1x1(xr, wr, br)
+    ref.backward(gout.double())
+    assert _rel(xg.grad, xr.grad) < 1e-5 and _rel(conv.weight.grad, wr.grad) < 1e-5 and _rel(conv.bias.grad, br.grad) < 1e-5
+
+
+def _caption_batch(rng, n_pts, n_caps, d, device):
+    uniq = torch.nn.functional.normalize(torch.from_numpy(rng.normal(size=(n_caps // 2 + 1, d)).astype(np.float32)), dim=1)
+    emb = [[uniq[int(rng.integers(0, uniq.shape[0]))] for _ in range(n_caps)]]
+    idx = [[torch.from_numpy(rng.choice(n_pts, size=int(rng.integers(20, 200)), replace=False)) for _ in range(n_caps)]]
+    pi, co, npc = train.flatten_caption_indices(idx, torch.tensor([0, n_pts]))
+    return dict(embedding=[[e.to(device) for e in emb[0]]], point_indices=pi.to(device), caption_offsets=co,
+                num_points_per_caption=npc)
+
+
+def test_caption_loss_matches_a_direct_restatement(device):
+    rng = np.random.default_rng(0)
+    n, d = 4000, 64
+    feats = torch.from_numpy(rng.normal(size=(n, d)).astype(np.float32))
+    cd = _caption_batch(rng, n, 12, d, device)
+    text, seg, _ = train.unique_text_features(cd["embedding"])
+    fg = feats.to(device).requires_grad_(True)
+    loss = train.caption_loss(fg, text, seg, cd["point_indices"], cd["caption_offsets"], cd["num_points_per_caption"])
+    loss.backward()
+    # restatement of caption_loss.py:212-235 in float64 on the CPU, caption by caption
+    fr = feats.double().requires_grad_(True)
+    scores = torch.log_softmax(torch.nn.functional.normalize(fr, dim=-1) @ text.cpu().double().T, dim=-1)
+    co, pi = cd["caption_offsets"], cd["point_indices"].cpu()
+    per = torch.stack([-scores[pi[co[s]:co[s + 1]]].mean(0)[seg[s].item()] for s in range(len(co) - 1)])
+    w = cd["num_points_per_caption"].double()
+    ref = (per * w).sum() / w.sum()
+    ref.backward()
+    assert abs(loss.item() - ref.item()) < 1e-5 * abs(ref.item())
+    assert _rel(fg.grad, fr.grad) < 1e-4
+
+
+class _CpuConvs:
+    """Runs a model built on sparse.py's modules on the CPU: voxelisation and every sparse convolution go
+    through the oracle (float64, torch autograd)."""
+
+    def __enter__(self):
+        self._fwd, self._sparsify = sparse.SparseConvolution.forward, spunet.SpUNet.sparsify
+
+        def sparsify(self_, input_dict, pad=128):
+            sp = oracle.sparsify(input_dict["coord"].numpy(), input_dict["feat"].numpy(), np.asarray(input_dict["offset"]),
+                                 input_dict["grid_size"], pad=pad)
+            x = sparse.SparseConvTensor(torch.from_numpy(sp["voxel_feats"]).double(), torch.from_numpy(sp["voxel_coords"]),
+                                        sp["spatial_shape"], sp["batch_size"])
+            return x, dict(v2p_map=torch.from_numpy(sp["v2p_map"]))
+
+        def forward(self_, x):
+            w = self_.weight
+            if self_.conv1x1:
+                return x.replace_feature(oracle.conv1x1(x.features, w, self_.bias))
+            key = ("oracle", self_.indice_key)
+            if self_.inverse:
+                pf, pb, idx, shape = x.indice_dict[key]
+                return sparse.SparseConvTensor(oracle.inverse_conv(x.features, w, pb, self_.bias), idx, shape, x.batch_size,
+                                               indice_dict=x.indice_dict)
+            if self_.subm:
+                if key not in x.indice_dict:
+                    x.indice_dict[key] = oracle.subm_rulebook(x.indices.numpy(), x.spatial_shape)
+                return x.replace_feature(oracle.subm_conv(x.features, w, x.indice_dict[key], self_.bias))
+            oi, oshape, pf, pb = oracle.strided_rulebook(x.indices.numpy(), x.spatial_shape)
+            x.indice_dict[key] = (pf, pb, x.indices, x.spatial_shape)
+            return sparse.SparseConvTensor(oracle.strided_conv(x.features, w, pf, self_.bias), torch.from_numpy(oi), oshape,
+                                           x.batch_size, indice_dict=x.indice_dict)
+
+        sparse.SparseConvolution.forward, spunet.SpUNet.sparsify = forward, sparsify
+        return self
+
+    def __exit__(self, *exc):
+        sparse.SparseConvolution.forward, spunet.SpUNet.sparsify = self._fwd, self._sparsify
+
+
+def test_whole_training_step_matches_cpu_oracle(device):
+    torch.manual_seed(0)
+    cfg = dict(spunet.SPUNET18A, out_channels=64, channels=(32, 64, 64, 96, 96, 64, 32, 32), layers=(1, 1, 1, 1, 1, 1, 1, 1))
+    net = spunet.PPT(spunet.SpUNet(in_channels=cfg["in_channels"], out_channels=cfg["out_channels"],
+                                   base_channels=cfg["base_channels"], context_channels=cfg["context_channels"],
+                                   channels=cfg["channels"], layers=cfg["layers"], zero_init=False))
+    ref = copy.deepcopy(net).double()
+    net = net.to(device)
+    sc = scenes.make_scene(seed=5, target_voxels=4000)
+    n = sc["coord"].shape[0]
+    rng = np.random.default_rng(1)
+    cd = _caption_batch(rng, n, 10, 64, device)
+    batch = dict(coord=torch.from_numpy(sc["coord"]).to(device), feat=torch.from_numpy(sc["feat"]).to(device),
+                 offset=torch.tensor([0, n]), grid_size=0.02, condition=["ScanNet"], caption_data=cd)
+    step = train.TrainStep(net, total_steps=10)
+    net.train()
+    loss = step.loss(batch)
+    loss.backward()
+    # the same on the CPU through the oracle
+    cdc = dict(embedding=[[e.cpu().double() for e in cd["embedding"][0]]], point_indices=cd["point_indices"].cpu(),
+               caption_offsets=cd["caption_offsets"], num_points_per_caption=cd["num_points_per_caption"])
+    bc = dict(coord=torch.from_numpy(sc["coord"]), feat=torch.from_numpy(sc["feat"]), offset=torch.tensor([0, n]),
+              grid_size=0.02, condition=["ScanNet"], caption_data=cdc)
+    ref.train()
+    with _CpuConvs():
+        out = ref(bc)
+        text, seg, _ = train.unique_text_features(cdc["embedding"])
+        loss_ref = train.caption_loss(out["sparse_conv_feat"].features[out["v2p_map"]], text, seg, cdc["point_indices"],
+                                      cdc["caption_offsets"], cdc["num_points_per_caption"])
+        loss_ref.backward()
+    assert abs(loss.item() - loss_ref.item()) < 1e-4 * abs(loss_ref.item())
+    checked = 0
+    for (name, p), (_, q) in zip(net.named_parameters(), ref.named_parameters()):
+        if q.grad is None:
+            assert p.grad is None or p.grad.abs().max() == 0, name
+            continue
+        assert p.grad is not None, name
+        if q.grad.norm() > 1e-12:
+            assert _rel(p.grad, q.grad) < 2e-3, (name, _rel(p.grad, q.grad))
+            checked += 1
+    assert checked > 40
+    # and the optimiser step runs and changes the weights
+    l1 = step(batch)
+    l2 = step(batch)
+    assert np.isfinite(l1) and np.isfinite(l2)

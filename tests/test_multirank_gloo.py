@@ -60,3 +60,33 @@ def test_two_ranks_gloo():
         assert t == 1.5                       # max over ranks
         assert u == float(sum(sizes))         # total units over ranks
         assert sorted(i for p in gathered for i in p) == list(range(7))
+
+
+def _grad_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from segmentation_amd import train
+        torch.manual_seed(0)  # same initial weights on every rank
+        net = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.ReLU(), torch.nn.Linear(16, 4))
+        x = torch.full((5, 8), float(rank + 1))
+        net(x).square().sum().backward()
+        local = [p.grad.clone() for p in net.parameters()]
+        nb = train.allreduce_gradients(list(net.parameters()), dist, bucket_bytes=256)  # several small buckets
+        out[rank] = (nb, local, [p.grad.clone() for p in net.parameters()])
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gradient_allreduce_two_ranks_gloo():
+    """The data-parallel gradient exchange of the training step: bucketed all-reduce, mean over ranks."""
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_grad_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    nb0, local0, avg0 = out[0]
+    nb1, local1, avg1 = out[1]
+    assert nb0 == nb1 and nb0 >= 2
+    for a, b, m0, m1 in zip(local0, local1, avg0, avg1):
+        assert torch.allclose(m0, (a + b) / 2) and torch.equal(m0, m1)
