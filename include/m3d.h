@@ -283,6 +283,15 @@ int m3d_argmax_rows(const float* d_logits, int64_t n_vox, int n_classes, int64_t
 int m3d_gather_labels(const int32_t* d_voxel_label, const int64_t* d_v2p_map, int64_t n_pts,
                       int64_t* d_point_label, void* stream);
 
+/* Average pooling over a kernel map.  Replaces spconv.pytorch.ops.indice_avgpool_implicit_gemm as OpenSegment3D's
+ * decoder uses it on the strided maps of the backbone
+ * (mosaic3d/src/models/networks/opensegment3d/model.py:272-276, :299-307):
+ *   out[o] = mean of in[pair[k][o]] over the k with pair[k][o] >= 0 (zero for a row without pairs);
+ *   d_pair [k, ld] i32 (ld = column stride), d_count [n_out] i32 receives the number of pairs (may be NULL).
+ */
+int m3d_avgpool_fwd(const float* d_in, int c, const int32_t* d_pair, int k, int64_t ld, int64_t n_out,
+                    float* d_out, int32_t* d_count, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

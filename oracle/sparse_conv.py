@@ -69,3 +69,18 @@ def dense_equivalent_strided(indices, feats, weight, spatial_shape, batch_size, 
     w = weight.double().permute(0, 4, 1, 2, 3)
     y = torch.nn.functional.conv3d(dense, w, stride=2)
     return y[oidx[:, 0], :, oidx[:, 1], oidx[:, 2], oidx[:, 3]]
+
+
+def avgpool(feats, pair, n_out=None):
+    """indice_avgpool_implicit_gemm: mean of feats[pair[k, o]] over the valid k (zero for rows without pairs).
+    spconv itself is absent: parity unpinned, this is the definition the GPU op is held to."""
+    pair_t = torch.as_tensor(np.asarray(pair), dtype=torch.int64)
+    n_out = pair_t.shape[1] if n_out is None else n_out
+    out = torch.zeros(n_out, feats.shape[1], dtype=torch.float64)
+    cnt = torch.zeros(n_out, dtype=torch.float64)
+    for k in range(pair_t.shape[0]):
+        p = pair_t[k, :n_out]
+        o = torch.nonzero(p >= 0).squeeze(1)
+        out.index_add_(0, o, feats.double().index_select(0, p[o]))
+        cnt.index_add_(0, o, torch.ones(o.numel(), dtype=torch.float64))
+    return out / cnt.clamp(min=1).unsqueeze(1), cnt.long()

@@ -11,9 +11,11 @@ import types
 from . import sparse
 
 
-def _indice_avgpool_implicit_gemm(*args, **kwargs):
-    raise NotImplementedError("spconv.pytorch.ops.indice_avgpool_implicit_gemm (OpenSegment3D decoder, "
-                              "mosaic3d/src/models/networks/opensegment3d/model.py:274-306) is not implemented")
+def _indice_avgpool_implicit_gemm(features, pair_fwd, num_out, calc_count=False):
+    """spconv.pytorch.ops.indice_avgpool_implicit_gemm as OpenSegment3D's decoder calls it
+    (mosaic3d/src/models/networks/opensegment3d/model.py:274-276, :301-306)."""
+    from . import ops
+    return ops.avgpool(features, pair_fwd, num_out, calc_count)
 
 
 def build_modules():

@@ -60,3 +60,38 @@ extern "C" int m3d_gather_labels(const int32_t* d_voxel_label, const int64_t* d_
   M3D_LAUNCH_CHECK();
   return M3D_OK;
 }
+
+// ------------------------------------------------------------------------------------------ average pooling
+// out[o][c] = mean over the kernel offsets k with pair[k][o] >= 0 of in[pair[k][o]][c]; rows without any pair
+// are zero.  One thread per (output row, channel); the pair column is read once per row from L1.
+namespace m3d {
+__global__ void avgpool_kernel(const float* __restrict__ in, int c, const int32_t* __restrict__ pair, int k, int64_t ld,
+                               int64_t n_out, float* __restrict__ out, int32_t* __restrict__ count) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_out * c) return;
+  const int64_t o = e / c;
+  const int ch = (int)(e % c);
+  float s = 0.f;
+  int cnt = 0;
+  for (int kk = 0; kk < k; ++kk) {
+    const int i = pair[(int64_t)kk * ld + o];
+    if (i >= 0) {
+      s += in[(int64_t)i * c + ch];
+      ++cnt;
+    }
+  }
+  out[e] = cnt ? s / (float)cnt : 0.f;
+  if (count && ch == 0) count[o] = cnt;
+}
+}  // namespace m3d
+
+extern "C" int m3d_avgpool_fwd(const float* d_in, int c, const int32_t* d_pair, int k, int64_t ld, int64_t n_out,
+                               float* d_out, int32_t* d_count, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  if (n_out == 0) return M3D_OK;
+  M3D_CHECK_ARG(d_in && d_pair && d_out && n_out > 0 && c >= 1 && k >= 1 && ld >= n_out, "m3d_avgpool_fwd: bad arguments");
+  hipLaunchKernelGGL(avgpool_kernel, dim3((unsigned)cdiv(n_out * c, 256)), dim3(256), 0, stream, d_in, c, d_pair, k, ld,
+                     n_out, d_out, d_count);
+  M3D_LAUNCH_CHECK();
+  return M3D_OK;
+}

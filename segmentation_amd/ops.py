@@ -440,3 +440,27 @@ def gather_labels(voxel_label, v2p_map):
     rc = lib.m3d_gather_labels(_ptr(voxel_label), _ptr(v2p_map.contiguous()), n, _ptr(out), _stream())
     _lib.check(rc, "m3d_gather_labels")
     return out
+
+
+def avgpool(features, pair_fwd, num_out=None, calc_count=False):
+    """spconv.pytorch.ops.indice_avgpool_implicit_gemm(features, pair_fwd, num_out, calc_count): mean of the input
+    rows every output row pairs with (opensegment3d/model.py:272-276,299-307).  Returns (out [num_out, C], count or None)."""
+    lib = _lib.load()
+    _need_cuda(features, pair_fwd)
+    if num_out is None:
+        num_out = pair_fwd.shape[1]
+    assert pair_fwd.dtype == torch.int32 and pair_fwd.dim() == 2 and pair_fwd.stride(1) == 1 and pair_fwd.shape[1] >= num_out
+    in_dtype = features.dtype
+    f = features.float().contiguous()
+    squeeze = f.dim() == 1
+    if squeeze:
+        f = f.unsqueeze(1)
+    c = f.shape[1]
+    out = torch.empty((num_out, c), dtype=torch.float32, device=f.device)
+    count = torch.empty((num_out,), dtype=torch.int32, device=f.device) if calc_count else None
+    rc = lib.m3d_avgpool_fwd(_ptr(f), c, _ptr(pair_fwd), pair_fwd.shape[0], pair_fwd.stride(0), num_out, _ptr(out),
+                             _ptr(count), _stream())
+    _lib.check(rc, "m3d_avgpool_fwd")
+    if squeeze:
+        out = out.squeeze(1)
+    return out.to(in_dtype), count

@@ -119,3 +119,21 @@ def test_schedule_is_a_permutation_of_the_kernel_map(device, mode):
         vc[:, 1:] >>= 6
         key = (morton_key(vc).astype(np.uint64) << np.uint64(20)) | pat
         assert np.array_equal(orow[:n], np.argsort(key, kind="stable"))
+
+
+def test_avgpool_over_the_strided_map(device):
+    """ops.avgpool (spconv.pytorch.ops.indice_avgpool_implicit_gemm) against the oracle; parity unpinned by the
+    reference (spconv absent), 1e-6 relative."""
+    from segmentation_amd import compat
+    sp = _voxels(7, 6000)
+    idx = torch.from_numpy(sp["voxel_coords"]).to(device)
+    oi, oshape, pf, pb = ops.strided_rulebook(idx, sp["spatial_shape"], 1)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(idx.shape[0], 37, generator=g)
+    fn = compat.build_modules()["spconv.pytorch.ops"].indice_avgpool_implicit_gemm
+    out, cnt = fn(x.to(device), pf, pf.shape[1], True)
+    ref, rcnt = oracle.sparse_conv.avgpool(x, pf.cpu().numpy())
+    assert out.shape == (oi.shape[0], 37) and np.array_equal(cnt.cpu().numpy(), rcnt.numpy())
+    assert ((out.cpu().double() - ref).abs().max() / ref.abs().max()).item() < 1e-6
+    out2, none = fn(x[:, 0].to(device), pf, pf.shape[1], False)
+    assert none is None and torch.allclose(out2.cpu(), out[:, 0].cpu())

@@ -43,8 +43,8 @@ def test_compat_aliases_resolve():
     assert spp.modules.is_spconv_module(sparse.SubMConv3d(4, 4, 3))
     assert not spp.modules.is_spconv_module(torch.nn.ReLU())
     assert hasattr(spp.core, "ImplicitGemmIndiceData")
-    with pytest.raises(NotImplementedError):
-        spp.ops.indice_avgpool_implicit_gemm()
+    with pytest.raises(RuntimeError, match="no CPU path"):  # the op exists and, like every op, refuses CPU tensors
+        spp.ops.indice_avgpool_implicit_gemm(torch.zeros(4, 2), torch.zeros((8, 2), dtype=torch.int32), 2, False)
     # the reference's isinstance-based init must not treat the other conv classes as SubMConv3d
     assert not isinstance(sparse.SparseConv3d(4, 4, 2, 2), sparse.SubMConv3d)
     assert not isinstance(sparse.SparseInverseConv3d(4, 4, 2, "k"), sparse.SubMConv3d)
@@ -94,3 +94,27 @@ def test_model_state_dict_matches_oracle_parameter_names():
     assert float(m2.enc[0].block0.bn1.modulation[1].weight.abs().max()) == 0.0
     n_params = sum(p.numel() for p in m2.parameters())
     assert 35e6 < n_params < 60e6
+
+
+def test_pred_record_and_label_ply_round_trip(tmp_path):
+    import numpy as np
+    import torch
+    from segmentation_amd import export
+    rng = np.random.default_rng(0)
+    coord = torch.from_numpy(rng.normal(size=(100, 3)).astype(np.float32))
+    pred = torch.from_numpy(rng.integers(0, 7, size=100))
+    logits = torch.from_numpy(rng.normal(size=(100, 7)).astype(np.float32))
+    p = export.save_pred(str(tmp_path / "pred" / "pred_0.pth"), coord, torch.tensor([100]), pred, logits,
+                         class_names=[f"c{i}" for i in range(7)])
+    rec = torch.load(p, map_location="cpu", weights_only=True)
+    assert sorted(rec) == ["class_names", "color", "coord", "logits", "pc_count", "pred"]  # language_module.py:349-356
+    pts, lab = export.load_pred_for_ply(p)
+    assert np.array_equal(pts, coord.numpy()) and np.array_equal(lab, pred.numpy())
+    ply = export.write_label_ply(str(tmp_path / "final_result.ply"), pts, lab, seed=3)
+    raw = open(ply, "rb").read()
+    head, body = raw.split(b"end_header\n", 1)
+    assert b"element vertex 100" in head and len(body) == 100 * 15
+    v = np.frombuffer(body, dtype=[("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("r", "u1"), ("g", "u1"), ("b", "u1")])
+    assert np.array_equal(v["x"], coord.numpy()[:, 0])
+    cm = export.class_colormap(int(lab.max()) + 1, 3)
+    assert np.array_equal(v["r"], (cm[lab, 0] * 255).astype(np.uint8))
