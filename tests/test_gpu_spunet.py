@@ -73,13 +73,16 @@ def test_module_path_matches_oracle(device, case):
     assert _rel_rows(feats, out["feat"].cpu()) < 1e-4
 
 
-def test_forward_only_guard(device, case):
+def test_modules_run_with_and_without_gradients(device, case):
     from segmentation_amd import sparse
     conv = sparse.SubMConv3d(32, 32, 3, padding=1, bias=False, indice_key="k").to(device)
     idx = torch.tensor([[0, 1, 1, 1], [0, 1, 1, 2]], dtype=torch.int32, device=device)
     x = sparse.SparseConvTensor(torch.randn(2, 32, device=device), idx, [8, 8, 8], 1)
-    with pytest.raises(RuntimeError, match="forward-only"):
-        conv(x)
+    y_train = conv(x)                      # gradients enabled: the differentiable path
+    assert y_train.features.requires_grad
+    y_train.features.sum().backward()
+    assert conv.weight.grad is not None and conv.weight.grad.shape == conv.weight.shape
     with torch.no_grad():
-        y = conv(x)
-    assert y.features.shape == (2, 32) and "k" in x.indice_dict
+        y = conv(x)                        # inference kernels
+    assert y.features.shape == (2, 32) and "k" in x.indice_dict and not y.features.requires_grad
+    assert torch.allclose(y.features, y_train.features.detach(), rtol=1e-5, atol=1e-6)
