@@ -1,4 +1,4 @@
-"""BASELINE-size scene (configs[1]: ~273 k voxels, 725 k points) through size-independent properties, where the
+"""Benchmark-size scene (~273 k voxels, 725 k points) through size-independent properties, where the
 CPU oracle would take minutes: sortedness and uniqueness of the voxel keys, consistency of v2p_map, symmetry of
 the submanifold map, parent/child consistency of the strided maps, schedules being permutations, linearity of
 the convolution, determinism, and label agreement between the split-bf16 and the exact-f32 engines."""

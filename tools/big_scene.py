@@ -1,4 +1,4 @@
-"""BASELINE config 5: one large scene (~2 M voxels at 1 cm, 15 x 15 x 3 m room), C = 200, D = 768.
+"""The large-scene benchmark case: one scene (~2 M voxels at 1 cm, 15 x 15 x 3 m room), C = 200, D = 768.
 Prints throughput, level sizes and peak memory; checks labels against the exact-f32 engine."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

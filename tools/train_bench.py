@@ -1,4 +1,4 @@
-"""Training step timing (BASELINE config 4 shape): B scenes per GPU, spunet34c+ppt, 300 captions per scene with
+"""Training step timing (the training benchmark case): B scenes per GPU, spunet34c+ppt, 300 captions per scene with
 random point subsets and random unit text rows, fwd + bwd + gradient all-reduce + SGD.
 usage: python tools/train_bench.py [scenes_per_gpu] [target_voxels] [steps]   (torchrun for several ranks)"""
 import os, sys, time
