@@ -112,6 +112,40 @@ __device__ inline void conv_stage_tile(const ConvArgs& a, const floatx16 (&acc)[
 
 template <int BM, int BN, int NTHR>
 __device__ inline void conv_store_tile(const ConvArgs& a, const float* S, const int* orow_s, int col_base, int tid) {
+  if (a.out == nullptr && a.out_split != nullptr) {
+    // split output only: 8-channel pieces, one 16-byte store per term and thread
+    constexpr int CPR8 = BN / 8;
+    for (int e = tid; e < BM * CPR8; e += NTHR) {
+      const int r = e / CPR8, c8 = e % CPR8;
+      const int orow = orow_s[r];
+      if (orow < 0) continue;
+      const float4 v0 = *reinterpret_cast<const float4*>(S + r * BN + c8 * 8);
+      const float4 v1 = *reinterpret_cast<const float4*>(S + r * BN + c8 * 8 + 4);
+      float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+      const int col = col_base + c8 * 8;
+      if (a.residual) {
+        const float4* q = reinterpret_cast<const float4*>(a.residual + (int64_t)orow * a.cout + col);
+        const float4 q0 = q[0], q1 = q[1];
+        v[0] += q0.x; v[1] += q0.y; v[2] += q0.z; v[3] += q0.w;
+        v[4] += q1.x; v[5] += q1.y; v[6] += q1.z; v[7] += q1.w;
+      }
+      if (a.relu) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], 0.f);
+      }
+      char* base = a.out_split + (((int64_t)orow * (a.cout >> 5) + (col >> 5)) * a.terms) * 64 + (col & 31) * 2;
+      for (int t = 0; t < a.terms; ++t) {
+        bf16x8 q;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          q[i] = (__bf16)v[i];
+          v[i] -= (float)q[i];
+        }
+        *reinterpret_cast<bf16x8*>(base + t * 64) = q;
+      }
+    }
+    return;
+  }
   constexpr int CPR = BN / 4;  // 4-channel pieces per row: consecutive lanes store consecutive 16 B (f32) / 8 B (bf16)
   for (int e = tid; e < BM * CPR; e += NTHR) {
     const int r = e / CPR, c4 = e % CPR;
