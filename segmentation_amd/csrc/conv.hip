@@ -780,10 +780,23 @@ static int launch_dma(const ConvArgs& a, int nz, hipStream_t stream) {
   return launch_dma_n<WM, WN, NT, T, 2>(a, nz, stream);
 }
 
-// Tile configuration: the largest row tile that still yields >= ~2 workgroups per CU.
+// Tile configuration.  Column tile: the widest of 128/96/64/32 dividing cout.  Row tile and offset split:
+// short reductions (fewer than three 32-channel slabs per offset) start from 64-row tiles, longer ones from
+// 128-row tiles (the weight stream is amortised over more rows); the kernel offsets are split nz ways until
+// about two workgroups per CU exist, and the row tile only shrinks when even a 9-way split cannot get there.
 struct ConvPlan {
   int wm, wn, nt, nz;
 };
+
+static ConvPlan plan_for_tile(int bm, int bn, int nz) {
+  if (bm == 128) return ConvPlan{4, 1, bn / 32, nz};
+  if (bm == 64) {
+    if (bn == 128) return ConvPlan{2, 2, 2, nz};
+    if (bn == 64) return ConvPlan{2, 2, 1, nz};
+    return ConvPlan{2, 1, bn / 32, nz};  // 96 or 32 columns
+  }
+  return ConvPlan{1, bn / 32, 1, nz};
+}
 
 static ConvPlan plan_conv(int64_t npad, int cout, int kvol, int cin) {
   int bn;
@@ -792,27 +805,16 @@ static ConvPlan plan_conv(int64_t npad, int cout, int kvol, int cin) {
   else if (cout % 64 == 0) bn = 64;
   else bn = 32;
   const int64_t ncol = cout / bn;
-  ConvPlan p{4, 1, bn / 32, 1};
-  const int64_t target = 512;
-  if ((npad / 128) * ncol >= target) return p;
-  if ((npad / 64) * ncol >= target) {
-    if (bn == 128) return ConvPlan{2, 2, 2, 1};
-    if (bn == 64) return ConvPlan{2, 2, 1, 1};
-    if (bn == 96) return ConvPlan{2, 1, 3, 1};
-    return ConvPlan{2, 1, 1, 1};
+  const int64_t target = 480, enough = 400;
+  const int max_nz = kvol == 27 ? 9 : 1;  // strided and inverse maps have about one active offset per output tile
+  for (int bm = cin >= 96 ? 128 : 64; bm >= 32; bm /= 2) {
+    const int64_t blocks = (npad / bm) * ncol;
+    if (blocks >= target) return plan_for_tile(bm, bn, 1);
+    int64_t nz = (target + blocks / 2) / blocks;  // nearest split count
+    if (nz > max_nz) nz = max_nz;
+    if (blocks * nz >= enough || bm == 32) return plan_for_tile(bm, bn, (int)nz);
   }
-  // small level, long reduction (>= 8 channel slabs per offset): full-height tiles amortise the weight
-  // stream, the kernel offsets are split 9 ways for parallelism
-  if (kvol == 27 && cin >= 256 && (npad / 128) * ncol * 9 >= 256) return ConvPlan{4, 1, bn / 32, 9};
-  p = ConvPlan{1, bn / 32, 1, 1};
-  const int64_t blocks = (npad / 32) * ncol;
-  if (blocks < target && kvol > 1) {
-    int nz = (int)((target + blocks - 1) / blocks);
-    if (nz > kvol) nz = kvol;
-    if (nz > 9) nz = 9;
-    p.nz = nz;
-  }
-  return p;
+  return plan_for_tile(32, bn, 1);
 }
 
 int run_conv_halo(const ConvArgs& a, const int32_t* d_cnt, const int32_t* d_rows, const uint16_t* d_loc,
@@ -826,7 +828,8 @@ extern "C" size_t m3d_conv_workspace_bytes(int64_t n, int cout, int k) {
   const int64_t npad = m3d_schedule_npad(n);
   if (cout <= 0 || cout % 32 != 0) return 256;  // served by the direct kernel, which needs no scratch
   const int nz_short = plan_conv(npad, cout, k, 32).nz, nz_long = plan_conv(npad, cout, k, 1 << 20).nz;
-  const int nz = nz_short > nz_long ? nz_short : nz_long;  // the plan also depends on the input channels
+  int nz = nz_short > nz_long ? nz_short : nz_long;  // the plan also depends on the input channels
+  if (getenv("M3D_PLAN")) nz = k;
   if (nz <= 1) return 256;
   return align_up((size_t)nz * npad * cout * sizeof(float));
 }
@@ -859,6 +862,12 @@ static int run_conv(ConvArgs& a, int mode, bool mfma_ok, void* d_ws, size_t ws_b
     return M3D_OK;
   }
   ConvPlan p = plan_conv(a.npad, a.cout, a.kvol, a.c0 + a.c1);
+  if (const char* e = getenv("M3D_PLAN")) {  // experiment hook: "wm,wn,nt,nz"
+    ConvPlan q{};
+    if (sscanf(e, "%d,%d,%d,%d", &q.wm, &q.wn, &q.nt, &q.nz) == 4 && q.wm > 0 && q.wn > 0 && q.nt > 0 && 32 * q.nt * q.wn <= a.cout &&
+        a.cout % (32 * q.nt * q.wn) == 0 && a.npad % (32 * q.wm) == 0 && q.nz >= 1 && q.nz <= a.kvol)
+      p = q;
+  }
   if (mode >= 3 && p.wm == 1 && p.wn == 3) p = ConvPlan{1, 1, 3, p.nz};  // equal DMA count per wave
   if (p.nz > 1) {
     const size_t need = (size_t)p.nz * a.npad * a.cout * sizeof(float);
