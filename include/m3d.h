@@ -283,6 +283,26 @@ int m3d_argmax_rows(const float* d_logits, int64_t n_vox, int n_classes, int64_t
 int m3d_gather_labels(const int32_t* d_voxel_label, const int64_t* d_v2p_map, int64_t n_pts,
                       int64_t* d_point_label, void* stream);
 
+/* The same head in one pass: the backbone's last 1x1 layer (SpUNetBase.final, spconv_unet_v1m3_pdnorm.py:355-357
+ * and :406), the logits against the text embeddings (clip_alignment_loss.py:138-147) and logits.max(1)[1]
+ * (language_module.py:328), with the cmid-channel CLIP features kept on chip:
+ *
+ *   logits[v][j] = sum_m (scale[m] * (W1[m] . x[v]) + shift[m]) * text[j][m],   label[v] = first argmax_j (j < n_classes)
+ *
+ *   d_in_split   sf32 activations [n + 1][cin/32][2][32] bf16 (the split output of the last decoder block)
+ *   d_w1         m3d_conv_pack_weight(M3D_PREC_BF16X3) of the [cmid, 1, cin] weight
+ *   d_scale, d_shift [cmid] f32 or NULL (the layer's bias goes into d_shift)
+ *   d_text_packed m3d_head_pack_text output ([classes_padded][cmid] in the order the kernel consumes)
+ *   d_logits     [n, ldl] f32 or NULL;  d_voxel_label [n] i32 or NULL (at least one of the two)
+ * Products as in M3D_PREC_BF16X3.  Supported: cin 32/64/96/128, classes_padded 128/256, cmid % 32 == 0;
+ * anything else returns M3D_EINVAL (callers then chain m3d_conv_fwd_sf32 and m3d_argmax_rows). */
+size_t m3d_head_text_bytes(int classes_padded, int cmid);
+int m3d_head_pack_text(const float* d_text, int n_classes, int cmid, int classes_padded, void* d_out,
+                       void* stream);
+int m3d_head_fused_sf32(const void* d_in_split, int cin, int64_t n, const void* d_w1, const float* d_scale,
+                        const float* d_shift, int cmid, const void* d_text_packed, int classes_padded,
+                        int n_classes, float* d_logits, int64_t ldl, int32_t* d_voxel_label, void* stream);
+
 /* Average pooling over a kernel map.  Replaces spconv.pytorch.ops.indice_avgpool_implicit_gemm as OpenSegment3D's
  * decoder uses it on the strided maps of the backbone
  * (mosaic3d/src/models/networks/opensegment3d/model.py:272-276, :299-307):

@@ -55,6 +55,9 @@ SIGNATURES = {
     "m3d_argmax_rows": (_int, [_vp, _i64, _int, _i64, _vp, _vp]),
     "m3d_gather_labels": (_int, [_vp, _vp, _i64, _vp, _vp]),
     "m3d_avgpool_fwd": (_int, [_vp, _int, _vp, _int, _i64, _i64, _vp, _vp, _vp]),
+    "m3d_head_text_bytes": (_sz, [_int, _int]),
+    "m3d_head_pack_text": (_int, [_vp, _int, _int, _int, _vp, _vp]),
+    "m3d_head_fused_sf32": (_int, [_vp, _int, _i64, _vp, _vp, _vp, _int, _vp, _int, _int, _vp, _i64, _vp, _vp]),
 }
 
 _lib = None

@@ -365,7 +365,8 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvArgs& a) {
   constexpr int GRPB = G::PIECES * 16;  // bytes of one (row, 32-channel group) in HBM
   static_assert(BM * G::SLOTS % NTHR == 0 && BN * G::SLOTS % NTHR == 0, "every wave must issue the same DMA count");
   extern __shared__ __align__(16) char ldsb[];
-  int* idx_s = reinterpret_cast<int*>(ldsb + NBUF * BUF);  // [kvol][BM]
+  constexpr int RING = NBUF * BUF > BM * BN * 4 ? NBUF * BUF : BM * BN * 4;  // the output tile is staged here too
+  int* idx_s = reinterpret_cast<int*>(ldsb + RING);  // [kvol][BM]
   int* orow_s = idx_s + a.kvol * BM;
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -747,8 +748,8 @@ static int launch_split(const ConvArgs& a, int nz, hipStream_t stream) {
 template <int WM, int WN, int NT, int T, int NBUF>
 static int launch_dma_n(const ConvArgs& a, int nz, hipStream_t stream) {
   constexpr int BM = 32 * WM, BN = 32 * NT * WN, NTHR = 64 * WM * WN;
-  static_assert((size_t)BM * BN * sizeof(float) <= (size_t)NBUF * (BM + BN) * DmaGeom<T>::ROWB, "output tile must fit in the staging buffers");
-  const size_t lds = (size_t)NBUF * (BM + BN) * DmaGeom<T>::ROWB + (size_t)(a.kvol + 1) * BM * sizeof(int);
+  constexpr size_t ring = (size_t)NBUF * (BM + BN) * DmaGeom<T>::ROWB, tile = (size_t)BM * BN * sizeof(float);
+  const size_t lds = (ring > tile ? ring : tile) + (size_t)(a.kvol + 1) * BM * sizeof(int);
   static size_t attr_lds = 0;
   if (lds > attr_lds) {
     M3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_dma_kernel<WM, WN, NT, T, NBUF>),
@@ -897,6 +898,7 @@ static int run_conv(ConvArgs& a, int mode, bool mfma_ok, void* d_ws, size_t ws_b
     M3D_CASE_DMA(4, 1, 1) M3D_CASE_DMA(4, 1, 2) M3D_CASE_DMA(4, 1, 3) M3D_CASE_DMA(4, 1, 4)
     M3D_CASE_DMA(2, 2, 1) M3D_CASE_DMA(2, 2, 2) M3D_CASE_DMA(2, 1, 3) M3D_CASE_DMA(2, 1, 1)
     M3D_CASE_DMA(1, 4, 1) M3D_CASE_DMA(1, 1, 3) M3D_CASE_DMA(1, 2, 1) M3D_CASE_DMA(1, 1, 1)
+    M3D_CASE_DMA(4, 2, 4)
   }
 #undef M3D_CASE
 #undef M3D_CASE_DMA

@@ -1,0 +1,361 @@
+// Open-vocabulary head in one kernel: the last 1x1 layer (cin -> cmid CLIP channels), the logits against the
+// text embeddings (cmid -> classes) and the row argmax.  The cmid-channel features never leave the CU.
+//
+// One workgroup = 128 voxel rows (4 waves x 32 rows).  The reduction over the cmid features runs in tiles of 32
+// features ("stages"); per stage the workgroup streams by LDS-DMA
+//     W1 tile [32 features][cin]        (A operand of the first product)
+//     W2 tile [classes][32 features]    (B operand of the second product)
+// through a ring of three LDS buffers, and every wave
+//   1. forms F^T = W1 . X^T for its 32 rows (32x32x16 bf16 MFMA, operands swapped: M = feature, N = row), with the
+//      activation fragments X held in registers for the whole kernel,
+//   2. applies the per-feature affine, splits the f32 values into two bf16 terms IN REGISTERS - the
+//      accumulator of the swapped product (lane = row, registers = features) is, up to a fixed permutation of the
+//      features inside a 16-wide reduction step, the A-operand layout of the next MFMA; the text matrix is packed
+//      with that permutation (m3d_head_pack_text), so no transpose through LDS is needed,
+//   3. accumulates logits += F . W2 (M = row, N = class).
+// Products follow the split-bf16 scheme of the convolution kernels: (hi,lo) + (lo,hi) + (hi,hi), f32 accumulate.
+// Epilogue: optional f32 logits, and the first index of the row maximum over the real classes.
+#include "conv_shared.h"
+
+#include <type_traits>
+
+namespace m3d {
+
+struct HeadArgs {
+  const char* x;        // sf32 [n + 1][cin/32][2][32] bf16, row n zero
+  const char* w1;       // packed [cmid][cin/32][2][32] bf16
+  const char* w2;       // packed [classes_padded][cmid/32][2][32] bf16, features permuted inside each group of 32
+  const float* scale;   // [cmid] or nullptr
+  const float* shift;   // [cmid] or nullptr
+  float* logits;        // [n][ldl] or nullptr
+  int64_t ldl;
+  int32_t* label;       // [n] or nullptr
+  int64_t n;
+  int cmid, n_classes;
+};
+
+constexpr int kHeadMaxFeatures = 1024;  // cmid limit of the fused kernel (scale/shift staging)
+
+// packed position p of a 32-feature group <-> feature channel
+__host__ __device__ inline int head_perm_channel(int p) {
+  const int ks = p >> 4, hh = (p >> 3) & 1, i = p & 7;
+  return 16 * ks + 4 * hh + (i < 4 ? i : i + 4);
+}
+
+// text [n_classes][cmid] f32 -> [classes_padded][cmid/32][2][32] bf16 (rows >= n_classes zero)
+__global__ void head_pack_text_kernel(const float* __restrict__ text, int n_classes, int cmid, int classes_padded,
+                                      __bf16* __restrict__ out) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (int64_t)classes_padded * cmid) return;
+  const int j = (int)(e / cmid), q = (int)(e % cmid);
+  const int grp = q >> 5, p = q & 31;
+  float v = j < n_classes ? text[(int64_t)j * cmid + grp * 32 + head_perm_channel(p)] : 0.f;
+  __bf16* dst = out + ((int64_t)j * (cmid >> 5) + grp) * 64 + p;
+  const __bf16 hi = (__bf16)v;
+  dst[0] = hi;
+  dst[32] = (__bf16)(v - (float)hi);
+}
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// LDS read issued outside the compiler's view (it neither schedules it late nor guards it with a wait on the
+// LDS-DMA traffic); the value is only valid after an s_waitcnt that lists the destination as an operand.
+template <int OFF, class V>
+__device__ __forceinline__ void lds_read16(V& dst, uint32_t addr) {
+  static_assert(sizeof(V) == 16 && OFF >= 0 && OFF < 65536, "ds_read_b128 with an immediate offset");
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+}
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
+template <int G1, int NT2>
+__device__ __forceinline__ void head_fused_body(const HeadArgs& a) {
+  using G = DmaGeom<2>;
+  constexpr int NBUF = 3;
+  constexpr int W1_BYTES = 32 * G1 * G::ROWB, W2_BYTES = NT2 * 32 * G::ROWB, BUF = W1_BYTES + W2_BYTES;
+  constexpr int W1_V = 32 * G1 * G::SLOTS / 256, W2_V = NT2 * 32 * G::SLOTS / 256;  // DMA instructions per thread
+  constexpr int GI = W1_V + W2_V;
+  static_assert(GI < 64, "vmcnt is a 6-bit counter");
+  extern __shared__ __align__(16) char ldsb[];
+  // per-feature scale and shift; an array of its own, so that its reads are known not to touch the DMA buffers
+  __shared__ __align__(16) float aff_s[2 * kHeadMaxFeatures];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r32 = lane & 31, h = lane >> 5;
+  const uint32_t lds_base = (uint32_t)(uintptr_t)(lds_ptr_t)ldsb;
+  const uint32_t aff_lds = (uint32_t)(uintptr_t)(lds_ptr_t)aff_s + (uint32_t)(4 * h) * 4u;
+  const int64_t tile_base = (int64_t)blockIdx.x * 128;
+  const int nstage = a.cmid >> 5;
+
+  // activation fragments of this wave's 32 rows (rows past the end read the zero row)
+  bf16x8 xf[G1][2][2];
+  {
+    const int64_t row = tile_base + wave * 32 + r32;
+    const char* xp = a.x + (row < a.n ? row : a.n) * (int64_t)(G1 * G::ROWB);
+#pragma unroll
+    for (int g = 0; g < G1; ++g)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+          xf[g][ks][t] = *reinterpret_cast<const bf16x8*>(xp + g * G::ROWB + t * 64 + (ks * 2 + h) * 16);
+  }
+  for (int i = tid; i < a.cmid; i += 256) {
+    aff_s[i] = a.scale ? a.scale[i] : 1.f;
+    aff_s[kHeadMaxFeatures + i] = a.shift ? a.shift[i] : 0.f;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  // DMA addressing (loop invariant).  Slot e = v * 256 + tid of an image is (row e / 8, physical slot e % 8) and
+  // carries logical piece (e % 8) ^ swz(row).  W1 image rows: group * 32 + feature; W2 image rows: class.
+  uint32_t w1_src[W1_V], w2_src[W2_V];
+#pragma unroll
+  for (int v = 0; v < W1_V; ++v) {
+    const int e = v * 256 + tid, rr = e / G::SLOTS;
+    const int g = rr >> 5, m = rr & 31;
+    const int p = (e % G::SLOTS) ^ G::swz(rr);
+    w1_src[v] = (uint32_t)((m * G1 + g) * G::ROWB + p * 16);
+  }
+#pragma unroll
+  for (int v = 0; v < W2_V; ++v) {
+    const int e = v * 256 + tid, j = e / G::SLOTS;
+    const int p = (e % G::SLOTS) ^ G::swz(j);
+    w2_src[v] = (uint32_t)j * (uint32_t)(nstage * G::ROWB) + (uint32_t)(p * 16);
+  }
+  auto issue = [&](int s, int bi) {
+    char* buf = ldsb + bi * BUF;
+    const char* s1 = a.w1 + (int64_t)s * (32 * G1 * G::ROWB);
+    const char* s2 = a.w2 + (int64_t)s * G::ROWB;
+#pragma unroll
+    for (int v = 0; v < W1_V; ++v)
+      __builtin_amdgcn_global_load_lds(s1 + w1_src[v], (lds_ptr_t)(buf + (v * 256 + wave * 64) * 16), 16, 0, 0);
+#pragma unroll
+    for (int v = 0; v < W2_V; ++v)
+      __builtin_amdgcn_global_load_lds(s2 + w2_src[v], (lds_ptr_t)(buf + W1_BYTES + (v * 256 + wave * 64) * 16), 16, 0, 0);
+  };
+
+  // fragment read offsets: piece (t * 4 + ks * 2 + h) of image row (.. + r32)
+  uint32_t frag[2][2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+    for (int t = 0; t < 2; ++t) frag[ks][t] = r32 * G::ROWB + (((t * 4 + ks * 2 + h) ^ G::swz(r32)) * 16);
+
+  floatx16 acc[NT2];
+#pragma unroll
+  for (int i = 0; i < NT2; ++i)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
+
+  issue(0, 0);
+  if (nstage > 1) issue(1, 1);
+  for (int s = 0; s < nstage; ++s) {
+    if (s + 1 < nstage) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GI) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (s + 2 < nstage) issue(s + 2, (s + 2) % NBUF);
+
+    // All LDS reads of a stage are issued by hand, one step ahead of the products that consume them: with one
+    // wave per SIMD nothing else hides the LDS latency.  (LDS reads complete in order, so "at most 2 outstanding"
+    // after requesting step i + 1 means step i has arrived.)
+    const uint32_t sbuf = lds_base + (uint32_t)((s % NBUF) * BUF);
+    f32x4 sc[4], sh[4];
+    {
+      const uint32_t ap = aff_lds + (uint32_t)(s * 32) * 4u;
+      lds_read16<0>(sc[0], ap); lds_read16<32>(sc[1], ap); lds_read16<64>(sc[2], ap); lds_read16<96>(sc[3], ap);
+      lds_read16<kHeadMaxFeatures * 4>(sh[0], ap); lds_read16<kHeadMaxFeatures * 4 + 32>(sh[1], ap);
+      lds_read16<kHeadMaxFeatures * 4 + 64>(sh[2], ap); lds_read16<kHeadMaxFeatures * 4 + 96>(sh[3], ap);
+    }
+    const uint32_t p00 = sbuf + frag[0][0], p01 = sbuf + frag[0][1], p10 = sbuf + frag[1][0], p11 = sbuf + frag[1][1];
+    // Steps 0 .. 2 * G1 - 1 belong to the first product (W1 fragments), the rest to the second (W2 fragments);
+    // the fragments of step i live in ring slot i % 3 and are requested two steps ahead.
+    constexpr int NS1 = 2 * G1, NSTEP = 2 * G1 + 2 * NT2;
+    bf16x8 bh[3], bl[3];
+    auto request = [&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      if constexpr (i < NSTEP) {
+        constexpr int off = i < NS1 ? (i >> 1) * 32 * G::ROWB : W1_BYTES + ((i - NS1) >> 1) * 32 * G::ROWB;
+        if constexpr ((i & 1) == 0) {
+          lds_read16<off>(bh[i % 3], p00);
+          lds_read16<off>(bl[i % 3], p01);
+        } else {
+          lds_read16<off>(bh[i % 3], p10);
+          lds_read16<off>(bl[i % 3], p11);
+        }
+      }
+    };
+    auto arrive = [&](auto ic) {  // waits until step i's fragments are in their registers
+      constexpr int i = decltype(ic)::value;
+      if constexpr (i + 2 < NSTEP) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(bh[i % 3]), "+v"(bl[i % 3]));
+      else if constexpr (i + 1 < NSTEP) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(bh[i % 3]), "+v"(bl[i % 3]));
+      else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bh[i % 3]), "+v"(bl[i % 3]));
+    };
+
+    // 1. F^T tile: features x rows
+    floatx16 f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) f[j] = 0.f;
+    request(std::integral_constant<int, 0>{});
+    request(std::integral_constant<int, 1>{});
+    static_for<0, NS1>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      constexpr int g = i >> 1, ks = i & 1, c = i % 3;
+      request(std::integral_constant<int, i + 2>{});
+      arrive(ic);
+      f = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl[c], xf[g][ks][0], f, 0, 0, 0);
+      f = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[c], xf[g][ks][1], f, 0, 0, 0);
+      f = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[c], xf[g][ks][0], f, 0, 0, 0);
+    });
+    // 2. affine + split; register r holds feature (r & 3) + 8 * (r >> 2) + 4 * h of the tile.  (The scale/shift
+    // reads were issued before every fragment read of the first product, so they have arrived.)
+    asm volatile("" : "+v"(sc[0]), "+v"(sc[1]), "+v"(sc[2]), "+v"(sc[3]), "+v"(sh[0]), "+v"(sh[1]), "+v"(sh[2]), "+v"(sh[3]));
+    bf16x8 ah[2], al[2];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float v = f[4 * q + i] * sc[q][i] + sh[q][i];
+        const __bf16 hi = (__bf16)v;
+        ah[q >> 1][(q & 1) * 4 + i] = hi;
+        al[q >> 1][(q & 1) * 4 + i] = (__bf16)(v - (float)hi);
+      }
+    }
+    // 3. logits += F . W2
+    static_for<NS1, NSTEP>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      constexpr int nt = (i - NS1) >> 1, ks = i & 1, c = i % 3;
+      request(std::integral_constant<int, i + 2>{});
+      arrive(ic);
+      acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks], bl[c], acc[nt], 0, 0, 0);
+      acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ks], bh[c], acc[nt], 0, 0, 0);
+      acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks], bh[c], acc[nt], 0, 0, 0);
+    });
+  }
+
+  // epilogue: accumulator register r is row (r & 3) + 8 * (r >> 2) + 4 * h, class nt * 32 + r32
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int64_t row = tile_base + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+    const bool live = row < a.n;
+    if (a.logits && live) {
+#pragma unroll
+      for (int nt = 0; nt < NT2; ++nt) {
+        const int c = nt * 32 + r32;
+        if (c < a.ldl) a.logits[row * a.ldl + c] = acc[nt][r];
+      }
+    }
+    if (a.label) {
+      // first index of the maximum: the first real class is taken as is, later ones only when strictly greater
+      float best = 0.f;
+      int bi = 0x7FFFFFFF;
+#pragma unroll
+      for (int nt = 0; nt < NT2; ++nt) {
+        const int c = nt * 32 + r32;
+        const float v = acc[nt][r];
+        if (c < a.n_classes && (bi == 0x7FFFFFFF || v > best)) {
+          best = v;
+          bi = c;
+        }
+      }
+#pragma unroll
+      for (int sft = 1; sft < 32; sft <<= 1) {
+        const float ov = __shfl_xor(best, sft);
+        const int oi = __shfl_xor(bi, sft);
+        if (oi != 0x7FFFFFFF && (bi == 0x7FFFFFFF || ov > best || (ov == best && oi < bi))) {
+          best = ov;
+          bi = oi;
+        }
+      }
+      if (live && r32 == 0) a.label[row] = bi;
+    }
+  }
+}
+
+template <int G1, int NT2>
+__global__ __launch_bounds__(256) void head_fused_kernel(HeadArgs a) {
+  head_fused_body<G1, NT2>(a);
+}
+
+template <int G1, int NT2>
+static int launch_head(const HeadArgs& a, hipStream_t stream) {
+  constexpr int BUF = (32 * G1 + 32 * NT2) * DmaGeom<2>::ROWB;
+  const size_t lds = 3 * (size_t)BUF;
+  if (a.cmid > kHeadMaxFeatures) {
+    set_error("m3d_head_fused_sf32: at most %d feature channels (got %d)", kHeadMaxFeatures, a.cmid);
+    return M3D_EINVAL;
+  }
+  static size_t attr_lds = 0;
+  if (lds > attr_lds) {
+    M3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&head_fused_kernel<G1, NT2>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_lds = lds;
+  }
+  hipLaunchKernelGGL((head_fused_kernel<G1, NT2>), dim3((unsigned)cdiv(a.n, 128)), dim3(256), lds, stream, a);
+  M3D_LAUNCH_CHECK();
+  return M3D_OK;
+}
+
+}  // namespace m3d
+
+using namespace m3d;
+
+extern "C" size_t m3d_head_text_bytes(int classes_padded, int cmid) {
+  if (classes_padded <= 0 || cmid <= 0) return 0;
+  return (size_t)classes_padded * cmid * 2 * sizeof(__bf16);
+}
+
+extern "C" int m3d_head_pack_text(const float* d_text, int n_classes, int cmid, int classes_padded, void* d_out,
+                                  void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  M3D_CHECK_ARG(d_text && d_out, "m3d_head_pack_text: null pointer");
+  M3D_CHECK_ARG(n_classes >= 1 && n_classes <= classes_padded && classes_padded % 32 == 0 && cmid >= 32 && cmid % 32 == 0,
+                "m3d_head_pack_text: bad sizes");
+  const int64_t total = (int64_t)classes_padded * cmid;
+  hipLaunchKernelGGL(head_pack_text_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, stream, d_text, n_classes,
+                     cmid, classes_padded, static_cast<__bf16*>(d_out));
+  M3D_LAUNCH_CHECK();
+  return M3D_OK;
+}
+
+extern "C" int m3d_head_fused_sf32(const void* d_in_split, int cin, int64_t n, const void* d_w1, const float* d_scale,
+                                   const float* d_shift, int cmid, const void* d_text_packed, int classes_padded,
+                                   int n_classes, float* d_logits, int64_t ldl, int32_t* d_voxel_label,
+                                   void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  if (n == 0) return M3D_OK;
+  M3D_CHECK_ARG(d_in_split && d_w1 && d_text_packed, "m3d_head_fused_sf32: null pointer");
+  M3D_CHECK_ARG(d_logits || d_voxel_label, "m3d_head_fused_sf32: no output requested");
+  M3D_CHECK_ARG(n > 0 && cmid >= 32 && cmid % 32 == 0 && n_classes >= 1 && n_classes <= classes_padded,
+                "m3d_head_fused_sf32: bad sizes");
+  M3D_CHECK_ARG(d_logits == nullptr || ldl >= n_classes, "m3d_head_fused_sf32: logits rows shorter than n_classes");
+  HeadArgs a;
+  a.x = static_cast<const char*>(d_in_split);
+  a.w1 = static_cast<const char*>(d_w1);
+  a.w2 = static_cast<const char*>(d_text_packed);
+  a.scale = d_scale;
+  a.shift = d_shift;
+  a.logits = d_logits;
+  a.ldl = ldl;
+  a.label = d_voxel_label;
+  a.n = n;
+  a.cmid = cmid;
+  a.n_classes = n_classes;
+#define M3D_HEAD_CASE(CIN_, CP_) \
+  if (cin == CIN_ && classes_padded == CP_) return launch_head<CIN_ / 32, CP_ / 32>(a, stream);
+  M3D_HEAD_CASE(96, 256) M3D_HEAD_CASE(96, 128) M3D_HEAD_CASE(64, 256) M3D_HEAD_CASE(64, 128)
+  M3D_HEAD_CASE(128, 256) M3D_HEAD_CASE(128, 128) M3D_HEAD_CASE(32, 256) M3D_HEAD_CASE(32, 128)
+#undef M3D_HEAD_CASE
+  set_error("m3d_head_fused_sf32: no kernel for %d input channels and %d padded classes (supported: 32/64/96/128 "
+            "channels, 128/256 classes)", cin, classes_padded);
+  return M3D_EINVAL;
+}

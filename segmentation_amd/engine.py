@@ -75,6 +75,7 @@ class SpUNetEngine:
         self._terms = {"f32": 0, "bf16x3": 2, "bf16x6": 3}[precision]
         # with a split precision `final` also writes an sf32 copy of the features for the logits GEMM
         self.head_precision = precision
+        self.fuse_head = os.environ.get("M3D_FUSE_HEAD", "1") != "0"
         self.device = torch.device(device)
         self.channels, self.layers = tuple(cfg["channels"]), tuple(cfg["layers"])
         self.num_stages = len(self.layers) // 2
@@ -124,6 +125,10 @@ class SpUNetEngine:
         w[:c, 0] = emb
         self.text = _Conv(ops.pack_weight(w, self.head_precision), None, None)
         self.n_classes = c
+        # one-kernel head (last 1x1 layer + logits + argmax): 2-term split precision and supported shapes only
+        self.text_fused = None
+        if self._terms == 2 and self.fuse_head and ops.head_fused_supported(self.final.w.cin, c):
+            self.text_fused = ops.head_pack_text(emb)
         # folded head: logits = x96 . (E Wf)^T + E bf   (no nonlinearity between `final` and the head)
         wf = self._sd["final.weight"].reshape(self.final.cout, -1).double().to(self.device)
         wfold = torch.zeros((cpad, 1, wf.shape[1]), dtype=torch.float32, device=self.device)
@@ -191,7 +196,8 @@ class SpUNetEngine:
         else:
             res = x[0]
         t = self._conv(blk["conv1"], x, sched, n, x2=x2, relu=True, need_f32=self._terms == 0)
-        return self._conv(blk["conv2"], t, sched, n, residual=res, relu=True, need_f32=True)
+        return self._conv(blk["conv2"], t, sched, n, residual=res, relu=True,
+                          need_f32=last_needs_f32 or self._terms == 0)
 
     def backbone(self, voxel_feats, levels, keep=None):
         """SpUNetBase.forward after sparsify (v1m3:388-407).  Returns the activation pair of the last decoder
@@ -219,7 +225,10 @@ class SpUNetEngine:
                 keep[f"up.{s}"] = x[0]
             skip = skips.pop(-1)
             for i, blk in enumerate(self.dec[s]):
-                x = self._block(blk, x, levels[s].subm, levels[s].n, x2=skip if i == 0 else None)
+                # the network's last block feeds `final` / the head, which read the split copy only
+                last = s == 0 and i == len(self.dec[s]) - 1 and keep is None
+                x = self._block(blk, x, levels[s].subm, levels[s].n, x2=skip if i == 0 else None,
+                                last_needs_f32=not last)
             if keep is not None:
                 keep[f"dec.{s}"] = x[0]
         return x
@@ -250,7 +259,15 @@ class SpUNetEngine:
         """Per-point labels (int64), like logits.max(1)[1] on clip_feat @ emb_target.T."""
         if self.text is None:
             raise RuntimeError("call set_text_embeddings() first")
-        if fold_head:
+        vlabel = None
+        if self.text_fused is not None and not fold_head:
+            # `final`, the logits and the argmax in one kernel: the CLIP features stay on chip
+            vox, levels = self._voxelize_and_maps(coord, feat, offset, grid_size)
+            x = self.backbone(vox["voxel_feats"], levels)
+            vlabel, logits = ops.head_fused(x[1], self.final.w, self.text_fused, scale=self.final.scale,
+                                            shift=self.final.shift, want_logits=return_logits)
+            self.last_stats = dict(n_points=int(coord.shape[0]), n_voxels=[levels[l].n for l in range(len(levels))])
+        elif fold_head:
             vox, levels = self._voxelize_and_maps(coord, feat, offset, grid_size)
             x = self.backbone(vox["voxel_feats"], levels)
             t = self.text_folded
@@ -263,7 +280,8 @@ class SpUNetEngine:
                                               want_f32=False)
             src = pair[1] if self._terms else pair
             logits = ops.conv_fwd(src, self.text.w, None, self.last_stats["n_voxels"][0], flop_cout=self.n_classes)
-        vlabel = ops.argmax_rows(logits, self.n_classes)
+        if vlabel is None:
+            vlabel = ops.argmax_rows(logits, self.n_classes)
         plabel = ops.gather_labels(vlabel, vox["v2p_map"])
         out = dict(pred=plabel, voxel_pred=vlabel, v2p_map=vox["v2p_map"], n_voxels=vox["n_voxels"])
         if return_logits:

@@ -431,6 +431,55 @@ def argmax_rows(logits, n_classes):
     return label
 
 
+class PackedText:
+    """Text embeddings in the layout of the fused head kernel."""
+
+    def __init__(self, data, n_classes, classes_padded, cmid):
+        self.data, self.n_classes, self.classes_padded, self.cmid = data, n_classes, classes_padded, cmid
+
+
+def head_pack_text(text, classes_padded=None):
+    """text [n_classes, cmid] f32 -> PackedText (classes padded to 128 or 256)."""
+    lib = _lib.load()
+    _need_cuda(text)
+    text = text.contiguous().float()
+    c, d = text.shape
+    cp = classes_padded or (128 if c <= 128 else 256)
+    if c > cp or d % 32 != 0:
+        raise ValueError(f"head_pack_text: {c} classes x {d} channels not supported")
+    out = torch.empty((lib.m3d_head_text_bytes(cp, d),), dtype=torch.uint8, device=text.device)
+    rc = lib.m3d_head_pack_text(_ptr(text), c, d, cp, _ptr(out), _stream())
+    _lib.check(rc, "m3d_head_pack_text")
+    return PackedText(out, c, cp, d)
+
+
+def head_fused_supported(cin, n_classes):
+    return cin in (32, 64, 96, 128) and n_classes <= 256
+
+
+def head_fused(x: "SplitTensor", w1: "PackedWeight", text: PackedText, scale=None, shift=None, want_logits=False,
+               want_labels=True):
+    """Last 1x1 layer + text logits + row argmax in one kernel.  Returns (voxel_label or None, logits or None)."""
+    lib = _lib.load()
+    assert x.terms == 2 and w1.precision == "bf16x3" and w1.k == 1 and w1.cout == text.cmid and w1.cin == x.c
+    n, dev = x.n, x.data.device
+    label = torch.empty((n,), dtype=torch.int32, device=dev) if want_labels else None
+    logits = torch.empty((n, text.classes_padded), dtype=torch.float32, device=dev) if want_logits else None
+    ev = None
+    if PROFILE is not None:
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
+    rc = lib.m3d_head_fused_sf32(_ptr(x.data), x.c, n, _ptr(w1.data), _ptr(scale), _ptr(shift), text.cmid,
+                                 _ptr(text.data), text.classes_padded, text.n_classes, _ptr(logits),
+                                 text.classes_padded, _ptr(label), _stream())
+    _lib.check(rc, "m3d_head_fused_sf32")
+    if ev is not None:
+        ev[1].record()
+        flops = 2.0 * n * text.cmid * (x.c + text.n_classes)
+        PROFILE.append(("head", flops, ev[0], ev[1], (n, x.c, text.n_classes, 1)))
+    return label, logits
+
+
 def gather_labels(voxel_label, v2p_map):
     lib = _lib.load()
     _need_cuda(voxel_label, v2p_map)

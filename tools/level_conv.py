@@ -1,14 +1,14 @@
 """One convolution on level L of the benchmark scene under forced tile plans:
 python3 tools/level_conv.py LEVEL[d|u] CIN COUT "wm,wn,nt,nz" ["wm,wn,nt,nz" ...]   ("-" = the library's own plan).
-LEVEL alone is the submanifold conv on that level; "Ld" the strided conv L -> L+1, "Lu" the inverse conv L+1 -> L."""
+LEVEL alone is the submanifold conv on that level; "Lh" a dense (k = 1) layer on its rows; "Ld" the strided conv L -> L+1, "Lu" the inverse conv L+1 -> L."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import bench
 from segmentation_amd import ops, scenes
 
-kind = sys.argv[1][-1] if sys.argv[1][-1] in "du" else "s"
-level, cin, cout = int(sys.argv[1].rstrip("du")), int(sys.argv[2]), int(sys.argv[3])
+kind = sys.argv[1][-1] if sys.argv[1][-1] in "duh" else "s"
+level, cin, cout = int(sys.argv[1].rstrip("duh")), int(sys.argv[2]), int(sys.argv[3])
 plans = sys.argv[4:] or ["-"]
 os.environ["M3D_PLAN"] = "0,0,0,0"  # sizes the workspace for any split count; an invalid plan is ignored
 dev = torch.device("cuda:0")
@@ -18,7 +18,8 @@ n = sc["coord"].shape[0]
 vox = ops.voxelize(torch.from_numpy(sc["coord"]).to(dev), torch.from_numpy(sc["feat"]).to(dev), np.array([0, n]), 0.02)
 levels = eng.build_levels(vox["voxel_coords"], vox["spatial_shape"], 1)
 lv = levels[level]
-sched, N, n_in, k = {"s": (lv.subm, lv.n, lv.n, 27), "d": (lv.down, lv.n_next, lv.n, 8), "u": (lv.up, lv.n, lv.n_next, 8)}[kind]
+sched, N, n_in, k = {"s": (lv.subm, lv.n, lv.n, 27), "d": (lv.down, lv.n_next, lv.n, 8), "u": (lv.up, lv.n, lv.n_next, 8),
+                     "h": (None, lv.n, lv.n, 1)}[kind]
 x = ops.split_f32(torch.randn(n_in, cin, device=dev), 2)
 w = ops.pack_weight(torch.randn(cout, k, cin) * 0.03, "bf16x3", dev)
 ref = None
