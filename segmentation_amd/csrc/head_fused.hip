@@ -1,18 +1,22 @@
 // Open-vocabulary head in one kernel: the last 1x1 layer (cin -> cmid CLIP channels), the logits against the
 // text embeddings (cmid -> classes) and the row argmax.  The cmid-channel features never leave the CU.
 //
-// One workgroup = 128 voxel rows (4 waves x 32 rows).  The reduction over the cmid features runs in tiles of 32
-// features ("stages"); per stage the workgroup streams by LDS-DMA
+// One workgroup = NW waves x 32 voxel rows (NW = 8 where the DMA slot count divides by 512 threads, else 4).  The
+// reduction over the cmid features runs in tiles of 32 features ("stages"); per stage the workgroup streams by
+// LDS-DMA
 //     W1 tile [32 features][cin]        (A operand of the first product)
 //     W2 tile [classes][32 features]    (B operand of the second product)
 // through a ring of three LDS buffers, and every wave
-//   1. forms F^T = W1 . X^T for its 32 rows (32x32x16 bf16 MFMA, operands swapped: M = feature, N = row), with the
-//      activation fragments X held in registers for the whole kernel,
-//   2. applies the per-feature affine, splits the f32 values into two bf16 terms IN REGISTERS - the
-//      accumulator of the swapped product (lane = row, registers = features) is, up to a fixed permutation of the
-//      features inside a 16-wide reduction step, the A-operand layout of the next MFMA; the text matrix is packed
-//      with that permutation (m3d_head_pack_text), so no transpose through LDS is needed,
-//   3. accumulates logits += F . W2 (M = row, N = class).
+//   A. forms F^T = W1 . X^T for its 32 rows (32x32x16 bf16 MFMA, operands swapped: M = feature, N = row), with the
+//      activation fragments X held in registers for the whole kernel; applies the per-feature affine and splits
+//      the f32 values into two bf16 terms IN REGISTERS - the accumulator of the swapped product (lane = row,
+//      registers = features) is, up to a fixed permutation of the features inside a 16-wide reduction step, the
+//      A-operand layout of the next MFMA; the text matrix is packed with that permutation (m3d_head_pack_text), so
+//      no transpose through LDS is needed,
+//   B. accumulates logits += F . W2 (M = row, N = class).
+// LDS allows one workgroup per CU, so the grid comes in rounds of one workgroup per CU.  The rows that would make
+// up a last, partly filled round are dealt in smaller pieces (32 * tail_waves rows per workgroup, the other waves
+// only help with the DMA), which costs about half a round instead of a whole one.
 // Products follow the split-bf16 scheme of the convolution kernels: (hi,lo) + (lo,hi) + (hi,hi), f32 accumulate.
 // Epilogue: optional f32 logits, and the first index of the row maximum over the real classes.
 #include "conv_shared.h"
@@ -32,6 +36,7 @@ struct HeadArgs {
   int32_t* label;       // [n] or nullptr
   int64_t n;
   int cmid, n_classes;
+  int full_blocks, tail_waves;  // workgroups below full_blocks take 32 * NW rows, the others 32 * tail_waves
 };
 
 constexpr int kHeadMaxFeatures = 1024;  // cmid limit of the fused kernel (scale/shift staging)
@@ -74,13 +79,14 @@ __device__ __forceinline__ void static_for(F&& f) {
   }
 }
 
-template <int G1, int NT2>
+template <int G1, int NT2, int NW>
 __device__ __forceinline__ void head_fused_body(const HeadArgs& a) {
   using G = DmaGeom<2>;
-  constexpr int NBUF = 3;
+  constexpr int NBUF = 3, NTHR = 64 * NW, ROWS = 32 * NW;
   constexpr int W1_BYTES = 32 * G1 * G::ROWB, W2_BYTES = NT2 * 32 * G::ROWB, BUF = W1_BYTES + W2_BYTES;
-  constexpr int W1_V = 32 * G1 * G::SLOTS / 256, W2_V = NT2 * 32 * G::SLOTS / 256;  // DMA instructions per thread
-  constexpr int GI = W1_V + W2_V;
+  constexpr int W1_SLOTS = 32 * G1 * G::SLOTS, SLOTS = W1_SLOTS + NT2 * 32 * G::SLOTS;
+  constexpr int GI = SLOTS / NTHR;  // DMA instructions per thread and stage
+  static_assert(SLOTS % NTHR == 0, "every wave must issue the same DMA count");
   static_assert(GI < 64, "vmcnt is a 6-bit counter");
   extern __shared__ __align__(16) char ldsb[];
   // per-feature scale and shift; an array of its own, so that its reads are known not to touch the DMA buffers
@@ -91,14 +97,17 @@ __device__ __forceinline__ void head_fused_body(const HeadArgs& a) {
   const int r32 = lane & 31, h = lane >> 5;
   const uint32_t lds_base = (uint32_t)(uintptr_t)(lds_ptr_t)ldsb;
   const uint32_t aff_lds = (uint32_t)(uintptr_t)(lds_ptr_t)aff_s + (uint32_t)(4 * h) * 4u;
-  const int64_t tile_base = (int64_t)blockIdx.x * 128;
+  const bool tail = (int)blockIdx.x >= a.full_blocks;
+  const int64_t tile_base = tail ? (int64_t)a.full_blocks * ROWS + (int64_t)((int)blockIdx.x - a.full_blocks) * (32 * a.tail_waves)
+                                 : (int64_t)blockIdx.x * ROWS;
+  const bool active = !tail || wave < a.tail_waves;  // inactive waves only take part in the DMA and the barriers
   const int nstage = a.cmid >> 5;
 
   // activation fragments of this wave's 32 rows (rows past the end read the zero row)
   bf16x8 xf[G1][2][2];
   {
     const int64_t row = tile_base + wave * 32 + r32;
-    const char* xp = a.x + (row < a.n ? row : a.n) * (int64_t)(G1 * G::ROWB);
+    const char* xp = a.x + (active && row < a.n ? row : a.n) * (int64_t)(G1 * G::ROWB);
 #pragma unroll
     for (int g = 0; g < G1; ++g)
 #pragma unroll
@@ -107,39 +116,40 @@ __device__ __forceinline__ void head_fused_body(const HeadArgs& a) {
         for (int t = 0; t < 2; ++t)
           xf[g][ks][t] = *reinterpret_cast<const bf16x8*>(xp + g * G::ROWB + t * 64 + (ks * 2 + h) * 16);
   }
-  for (int i = tid; i < a.cmid; i += 256) {
+  for (int i = tid; i < a.cmid; i += NTHR) {
     aff_s[i] = a.scale ? a.scale[i] : 1.f;
     aff_s[kHeadMaxFeatures + i] = a.shift ? a.shift[i] : 0.f;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
-  // DMA addressing (loop invariant).  Slot e = v * 256 + tid of an image is (row e / 8, physical slot e % 8) and
-  // carries logical piece (e % 8) ^ swz(row).  W1 image rows: group * 32 + feature; W2 image rows: class.
-  uint32_t w1_src[W1_V], w2_src[W2_V];
+  // DMA addressing (loop invariant).  The W1 image (rows: group * 32 + feature) and the W2 image (rows: class) sit
+  // back to back in a buffer and are filled as one list of 16-byte slots: slot e = v * NTHR + tid is (image row
+  // e / 8, physical slot e % 8) and carries logical piece (e % 8) ^ swz(row).  Per stage the W1 source advances by
+  // one 32-feature tile, the W2 source by one 32-feature group.
+  const char* src0[GI];
+  uint32_t step[GI];
 #pragma unroll
-  for (int v = 0; v < W1_V; ++v) {
-    const int e = v * 256 + tid, rr = e / G::SLOTS;
-    const int g = rr >> 5, m = rr & 31;
-    const int p = (e % G::SLOTS) ^ G::swz(rr);
-    w1_src[v] = (uint32_t)((m * G1 + g) * G::ROWB + p * 16);
-  }
-#pragma unroll
-  for (int v = 0; v < W2_V; ++v) {
-    const int e = v * 256 + tid, j = e / G::SLOTS;
-    const int p = (e % G::SLOTS) ^ G::swz(j);
-    w2_src[v] = (uint32_t)j * (uint32_t)(nstage * G::ROWB) + (uint32_t)(p * 16);
+  for (int v = 0; v < GI; ++v) {
+    const int e = v * NTHR + tid;
+    if (e < W1_SLOTS) {
+      const int rr = e / G::SLOTS, g = rr >> 5, m = rr & 31;
+      const int p = (e % G::SLOTS) ^ G::swz(rr);
+      src0[v] = a.w1 + ((m * G1 + g) * G::ROWB + p * 16);
+      step[v] = 32 * G1 * G::ROWB;
+    } else {
+      const int e2 = e - W1_SLOTS, j = e2 / G::SLOTS;
+      const int p = (e2 % G::SLOTS) ^ G::swz(j);
+      src0[v] = a.w2 + ((int64_t)j * nstage * G::ROWB + p * 16);
+      step[v] = G::ROWB;
+    }
   }
   auto issue = [&](int s, int bi) {
     char* buf = ldsb + bi * BUF;
-    const char* s1 = a.w1 + (int64_t)s * (32 * G1 * G::ROWB);
-    const char* s2 = a.w2 + (int64_t)s * G::ROWB;
 #pragma unroll
-    for (int v = 0; v < W1_V; ++v)
-      __builtin_amdgcn_global_load_lds(s1 + w1_src[v], (lds_ptr_t)(buf + (v * 256 + wave * 64) * 16), 16, 0, 0);
-#pragma unroll
-    for (int v = 0; v < W2_V; ++v)
-      __builtin_amdgcn_global_load_lds(s2 + w2_src[v], (lds_ptr_t)(buf + W1_BYTES + (v * 256 + wave * 64) * 16), 16, 0, 0);
+    for (int v = 0; v < GI; ++v)
+      __builtin_amdgcn_global_load_lds(src0[v] + (uint32_t)s * step[v], (lds_ptr_t)(buf + (v * NTHR + wave * 64) * 16),
+                                       16, 0, 0);
   };
 
   // fragment read offsets: piece (t * 4 + ks * 2 + h) of image row (.. + r32)
@@ -155,36 +165,18 @@ __device__ __forceinline__ void head_fused_body(const HeadArgs& a) {
 #pragma unroll
     for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
 
-  issue(0, 0);
-  if (nstage > 1) issue(1, 1);
-  for (int s = 0; s < nstage; ++s) {
-    if (s + 1 < nstage) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GI) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    if (s + 2 < nstage) issue(s + 2, (s + 2) % NBUF);
-
-    // All LDS reads of a stage are issued by hand, one step ahead of the products that consume them: with one
-    // wave per SIMD nothing else hides the LDS latency.  (LDS reads complete in order, so "at most 2 outstanding"
-    // after requesting step i + 1 means step i has arrived.)
-    const uint32_t sbuf = lds_base + (uint32_t)((s % NBUF) * BUF);
-    f32x4 sc[4], sh[4];
-    {
-      const uint32_t ap = aff_lds + (uint32_t)(s * 32) * 4u;
-      lds_read16<0>(sc[0], ap); lds_read16<32>(sc[1], ap); lds_read16<64>(sc[2], ap); lds_read16<96>(sc[3], ap);
-      lds_read16<kHeadMaxFeatures * 4>(sh[0], ap); lds_read16<kHeadMaxFeatures * 4 + 32>(sh[1], ap);
-      lds_read16<kHeadMaxFeatures * 4 + 64>(sh[2], ap); lds_read16<kHeadMaxFeatures * 4 + 96>(sh[3], ap);
-    }
+  // Fragment pipeline of one product: NSTEPS steps of (2 LDS reads, 3 MFMA); the reads are issued by hand two steps
+  // ahead of the products that consume them and waited for with counted lgkmcnt (LDS reads complete in order, so
+  // "at most 4 outstanding" after requesting step i + 2 means step i has arrived).  body(step, hi, lo) issues the
+  // three products of a step.
+  auto fragment_pipeline = [&](auto nsteps_c, auto base_off_c, uint32_t sbuf, auto&& body) {
+    constexpr int NSTEPS = decltype(nsteps_c)::value, BASE = decltype(base_off_c)::value;
     const uint32_t p00 = sbuf + frag[0][0], p01 = sbuf + frag[0][1], p10 = sbuf + frag[1][0], p11 = sbuf + frag[1][1];
-    // Steps 0 .. 2 * G1 - 1 belong to the first product (W1 fragments), the rest to the second (W2 fragments);
-    // the fragments of step i live in ring slot i % 3 and are requested two steps ahead.
-    constexpr int NS1 = 2 * G1, NSTEP = 2 * G1 + 2 * NT2;
     bf16x8 bh[3], bl[3];
     auto request = [&](auto ic) {
       constexpr int i = decltype(ic)::value;
-      if constexpr (i < NSTEP) {
-        constexpr int off = i < NS1 ? (i >> 1) * 32 * G::ROWB : W1_BYTES + ((i - NS1) >> 1) * 32 * G::ROWB;
+      if constexpr (i < NSTEPS) {
+        constexpr int off = BASE + (i >> 1) * 32 * G::ROWB;
         if constexpr ((i & 1) == 0) {
           lds_read16<off>(bh[i % 3], p00);
           lds_read16<off>(bl[i % 3], p01);
@@ -194,53 +186,82 @@ __device__ __forceinline__ void head_fused_body(const HeadArgs& a) {
         }
       }
     };
-    auto arrive = [&](auto ic) {  // waits until step i's fragments are in their registers
+    request(std::integral_constant<int, 0>{});
+    request(std::integral_constant<int, 1>{});
+    static_for<0, NSTEPS>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
-      if constexpr (i + 2 < NSTEP) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(bh[i % 3]), "+v"(bl[i % 3]));
-      else if constexpr (i + 1 < NSTEP) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(bh[i % 3]), "+v"(bl[i % 3]));
+      request(std::integral_constant<int, i + 2>{});
+      if constexpr (i + 2 < NSTEPS) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(bh[i % 3]), "+v"(bl[i % 3]));
+      else if constexpr (i + 1 < NSTEPS) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(bh[i % 3]), "+v"(bl[i % 3]));
       else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bh[i % 3]), "+v"(bl[i % 3]));
-    };
+      body(ic, bh[i % 3], bl[i % 3]);
+    });
+  };
 
-    // 1. F^T tile: features x rows
+  bf16x8 ah[2], al[2];  // the current feature tile as A operand: [reduction half] hi / lo terms
+
+  // A(s): F^T tile of features 32 s .. 32 s + 31 (features x rows), affine, split into ah / al
+  auto stage_a = [&](int s) {
     floatx16 f;
 #pragma unroll
     for (int j = 0; j < 16; ++j) f[j] = 0.f;
-    request(std::integral_constant<int, 0>{});
-    request(std::integral_constant<int, 1>{});
-    static_for<0, NS1>([&](auto ic) {
-      constexpr int i = decltype(ic)::value;
-      constexpr int g = i >> 1, ks = i & 1, c = i % 3;
-      request(std::integral_constant<int, i + 2>{});
-      arrive(ic);
-      f = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl[c], xf[g][ks][0], f, 0, 0, 0);
-      f = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[c], xf[g][ks][1], f, 0, 0, 0);
-      f = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[c], xf[g][ks][0], f, 0, 0, 0);
-    });
-    // 2. affine + split; register r holds feature (r & 3) + 8 * (r >> 2) + 4 * h of the tile.  (The scale/shift
-    // reads were issued before every fragment read of the first product, so they have arrived.)
-    asm volatile("" : "+v"(sc[0]), "+v"(sc[1]), "+v"(sc[2]), "+v"(sc[3]), "+v"(sh[0]), "+v"(sh[1]), "+v"(sh[2]), "+v"(sh[3]));
-    bf16x8 ah[2], al[2];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    fragment_pipeline(std::integral_constant<int, 2 * G1>{}, std::integral_constant<int, 0>{},
+                      lds_base + (uint32_t)((s % NBUF) * BUF), [&](auto ic, const bf16x8& wh, const bf16x8& wl) {
+                        constexpr int i = decltype(ic)::value, g = i >> 1, ks = i & 1;
+                        f = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, xf[g][ks][0], f, 0, 0, 0);
+                        f = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xf[g][ks][1], f, 0, 0, 0);
+                        f = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xf[g][ks][0], f, 0, 0, 0);
+                      });
+    // register r holds feature (r & 3) + 8 * (r >> 2) + 4 * h of the tile
+    const uint32_t ap = aff_lds + (uint32_t)(s * 32) * 4u;
+    static_for<0, 4>([&](auto qc) {
+      constexpr int q = decltype(qc)::value;
+      f32x4 sc, sh;
+      lds_read16<q * 32>(sc, ap);
+      lds_read16<kHeadMaxFeatures * 4 + q * 32>(sh, ap);
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(sc), "+v"(sh));
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const float v = f[4 * q + i] * sc[q][i] + sh[q][i];
+        const float v = f[4 * q + i] * sc[i] + sh[i];
         const __bf16 hi = (__bf16)v;
         ah[q >> 1][(q & 1) * 4 + i] = hi;
         al[q >> 1][(q & 1) * 4 + i] = (__bf16)(v - (float)hi);
       }
-    }
-    // 3. logits += F . W2
-    static_for<NS1, NSTEP>([&](auto ic) {
-      constexpr int i = decltype(ic)::value;
-      constexpr int nt = (i - NS1) >> 1, ks = i & 1, c = i % 3;
-      request(std::integral_constant<int, i + 2>{});
-      arrive(ic);
-      acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks], bl[c], acc[nt], 0, 0, 0);
-      acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ks], bh[c], acc[nt], 0, 0, 0);
-      acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks], bh[c], acc[nt], 0, 0, 0);
     });
+  };
+  // B(s): logits += F tile . W2 tile s
+  auto stage_b = [&](int s) {
+    fragment_pipeline(std::integral_constant<int, 2 * NT2>{}, std::integral_constant<int, W1_BYTES>{},
+                      lds_base + (uint32_t)((s % NBUF) * BUF), [&](auto ic, const bf16x8& bh, const bf16x8& bl) {
+                        constexpr int i = decltype(ic)::value, nt = i >> 1, ks = i & 1;
+                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks], bl, acc[nt], 0, 0, 0);
+                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ks], bh, acc[nt], 0, 0, 0);
+                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks], bh, acc[nt], 0, 0, 0);
+                      });
+  };
+
+  // Stage loop.  sync(k), once per stage and wave: tile k has landed for every wave, and every wave is done with
+  // tile k - 2, whose buffer then receives tile k + 1.  The lower half of the waves syncs between stages
+  // (.. A(s) B(s) | A(s+1) ..), the upper half between the two products (.. A(s) | B(s) A(s+1) | ..): on every SIMD
+  // one wave is in the MFMA-dense product B while its partner is in A (short dependent MFMA chain, VALU split) or
+  // issuing DMA.
+  auto sync = [&](int k) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (k + 1 < nstage) issue(k + 1, (k + 1) % NBUF);
+  };
+  const bool rotated = NW == 8 && wave >= 4;
+  issue(0, 0);
+  sync(0);
+  for (int s = 0; s < nstage; ++s) {
+    if (active) stage_a(s);
+    if (rotated) sync(s + 1);
+    if (active) stage_b(s);
+    if (!rotated) sync(s + 1);
   }
+  if (!active) return;
 
   // epilogue: accumulator register r is row (r & 3) + 8 * (r >> 2) + 4 * h, class nt * 32 + r32
 #pragma unroll
@@ -281,26 +302,41 @@ __device__ __forceinline__ void head_fused_body(const HeadArgs& a) {
   }
 }
 
-template <int G1, int NT2>
-__global__ __launch_bounds__(256) void head_fused_kernel(HeadArgs a) {
-  head_fused_body<G1, NT2>(a);
+template <int G1, int NT2, int NW>
+__global__ __launch_bounds__(64 * NW) void head_fused_kernel(HeadArgs a) {
+  head_fused_body<G1, NT2, NW>(a);
 }
 
-template <int G1, int NT2>
+template <int G1, int NT2, int NW>
 static int launch_head(const HeadArgs& a, hipStream_t stream) {
   constexpr int BUF = (32 * G1 + 32 * NT2) * DmaGeom<2>::ROWB;
   const size_t lds = 3 * (size_t)BUF;
-  if (a.cmid > kHeadMaxFeatures) {
-    set_error("m3d_head_fused_sf32: at most %d feature channels (got %d)", kHeadMaxFeatures, a.cmid);
-    return M3D_EINVAL;
-  }
   static size_t attr_lds = 0;
   if (lds > attr_lds) {
-    M3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&head_fused_kernel<G1, NT2>),
+    M3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&head_fused_kernel<G1, NT2, NW>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_lds = lds;
   }
-  hipLaunchKernelGGL((head_fused_kernel<G1, NT2>), dim3((unsigned)cdiv(a.n, 128)), dim3(256), lds, stream, a);
+  // rounds of one workgroup per CU; what is left after the full rounds goes out in pieces small enough for one round
+  static const int ncu = [] {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+      v = 256;
+    return v > 0 ? v : 256;
+  }();
+  constexpr int ROWS = 32 * NW;
+  HeadArgs b = a;
+  const int64_t blocks = cdiv(a.n, ROWS);
+  b.full_blocks = (int)(blocks / ncu * ncu);
+  b.tail_waves = NW;
+  const int64_t rest = a.n - (int64_t)b.full_blocks * ROWS;
+  if (rest > 0) {
+    const int64_t k = cdiv(rest, (int64_t)32 * ncu);  // waves per workgroup that cover the rest in one round
+    if (k < NW) b.tail_waves = (int)k;
+  }
+  const int64_t tail_blocks = rest > 0 ? cdiv(rest, (int64_t)32 * b.tail_waves) : 0;
+  hipLaunchKernelGGL((head_fused_kernel<G1, NT2, NW>), dim3((unsigned)(b.full_blocks + tail_blocks)), dim3(64 * NW), lds,
+                     stream, b);
   M3D_LAUNCH_CHECK();
   return M3D_OK;
 }
@@ -350,12 +386,19 @@ extern "C" int m3d_head_fused_sf32(const void* d_in_split, int cin, int64_t n, c
   a.n = n;
   a.cmid = cmid;
   a.n_classes = n_classes;
-#define M3D_HEAD_CASE(CIN_, CP_) \
-  if (cin == CIN_ && classes_padded == CP_) return launch_head<CIN_ / 32, CP_ / 32>(a, stream);
-  M3D_HEAD_CASE(96, 256) M3D_HEAD_CASE(96, 128) M3D_HEAD_CASE(64, 256) M3D_HEAD_CASE(64, 128)
-  M3D_HEAD_CASE(128, 256) M3D_HEAD_CASE(128, 128) M3D_HEAD_CASE(32, 256) M3D_HEAD_CASE(32, 128)
+  if (cmid > kHeadMaxFeatures) {
+    set_error("m3d_head_fused_sf32: at most %d feature channels (got %d)", kHeadMaxFeatures, cmid);
+    return M3D_EINVAL;
+  }
+  // 8 waves x 32 rows per workgroup where the DMA slot count divides by 512 threads, else 4 waves
+#define M3D_HEAD_CASE(CIN_, CP_, NW_) \
+  if (cin == CIN_ && classes_padded == CP_) return launch_head<CIN_ / 32, CP_ / 32, NW_>(a, stream);
+  M3D_HEAD_CASE(96, 32, 8) M3D_HEAD_CASE(96, 96, 8) M3D_HEAD_CASE(96, 160, 8) M3D_HEAD_CASE(96, 224, 8)
+  M3D_HEAD_CASE(96, 64, 4) M3D_HEAD_CASE(96, 128, 4) M3D_HEAD_CASE(96, 192, 4) M3D_HEAD_CASE(96, 256, 4)
+  M3D_HEAD_CASE(32, 128, 4) M3D_HEAD_CASE(32, 256, 4) M3D_HEAD_CASE(64, 128, 8) M3D_HEAD_CASE(64, 256, 8)
+  M3D_HEAD_CASE(128, 128, 8) M3D_HEAD_CASE(128, 256, 4)
 #undef M3D_HEAD_CASE
-  set_error("m3d_head_fused_sf32: no kernel for %d input channels and %d padded classes (supported: 32/64/96/128 "
-            "channels, 128/256 classes)", cin, classes_padded);
+  set_error("m3d_head_fused_sf32: no kernel for %d input channels and %d padded classes (supported: 96 channels "
+            "with 32..256 classes in steps of 32; 32/64/128 channels with 128 or 256 classes)", cin, classes_padded);
   return M3D_EINVAL;
 }

@@ -128,7 +128,7 @@ class SpUNetEngine:
         # one-kernel head (last 1x1 layer + logits + argmax): 2-term split precision and supported shapes only
         self.text_fused = None
         if self._terms == 2 and self.fuse_head and ops.head_fused_supported(self.final.w.cin, c):
-            self.text_fused = ops.head_pack_text(emb)
+            self.text_fused = ops.head_pack_text(emb, cin=self.final.w.cin)
         # folded head: logits = x96 . (E Wf)^T + E bf   (no nonlinearity between `final` and the head)
         wf = self._sd["final.weight"].reshape(self.final.cout, -1).double().to(self.device)
         wfold = torch.zeros((cpad, 1, wf.shape[1]), dtype=torch.float32, device=self.device)

@@ -438,13 +438,14 @@ class PackedText:
         self.data, self.n_classes, self.classes_padded, self.cmid = data, n_classes, classes_padded, cmid
 
 
-def head_pack_text(text, classes_padded=None):
-    """text [n_classes, cmid] f32 -> PackedText (classes padded to 128 or 256)."""
+def head_pack_text(text, cin=96, classes_padded=None):
+    """text [n_classes, cmid] f32 -> PackedText.  The class count is padded to what the fused kernel for `cin`
+    input channels takes: a multiple of 32 for 96 channels, 128 or 256 otherwise."""
     lib = _lib.load()
     _need_cuda(text)
     text = text.contiguous().float()
     c, d = text.shape
-    cp = classes_padded or (128 if c <= 128 else 256)
+    cp = classes_padded or ((c + 31) // 32 * 32 if cin == 96 else (128 if c <= 128 else 256))
     if c > cp or d % 32 != 0:
         raise ValueError(f"head_pack_text: {c} classes x {d} channels not supported")
     out = torch.empty((lib.m3d_head_text_bytes(cp, d),), dtype=torch.uint8, device=text.device)

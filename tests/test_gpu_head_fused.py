@@ -27,16 +27,20 @@ def _case(device, n, cin, cmid, ncls, seed, affine=True):
 
 
 @pytest.mark.parametrize("n,cin,cmid,ncls", [(1000, 96, 768, 200), (129, 96, 768, 200), (4096, 64, 64, 20),
-                                             (777, 128, 256, 128), (300, 32, 96, 129)])
+                                             (777, 128, 256, 128), (300, 32, 96, 129), (2000, 96, 768, 256),
+                                             (513, 96, 512, 20), (700, 96, 768, 150), (640, 128, 1024, 256),
+                                             (900, 64, 768, 200), (70000, 96, 768, 200),
+                                             (40000, 32, 64, 100)])
 def test_fused_head_matches_float64(device, n, cin, cmid, ncls):
     c = _case(device, n, cin, cmid, ncls, seed=n)
     xs = ops.split_f32(c["x"], 2)
     w1 = ops.pack_weight(c["w1"], "bf16x3", device)
-    tp = ops.head_pack_text(c["text"])
+    tp = ops.head_pack_text(c["text"], cin=cin)
     label, logits = ops.head_fused(xs, w1, tp, scale=c["scale"], shift=c["shift"], want_logits=True)
     got = logits[:, :ncls].double().cpu()
     rel = ((got - c["ref"]).norm(dim=1) / c["ref"].norm(dim=1)).max().item()
     assert rel < 1e-4, rel
+    assert logits.shape[1] == tp.classes_padded and tp.classes_padded % 32 == 0
     assert torch.equal(label.cpu().long(), logits[:, :ncls].cpu().argmax(dim=1))
     agree = (label.cpu().long() == c["ref"].argmax(dim=1)).float().mean().item()
     assert agree >= 0.999, agree
@@ -78,6 +82,6 @@ def test_fused_head_ties_take_the_first_class(device):
 def test_fused_head_rejects_unsupported_shapes(device):
     x = ops.split_f32(torch.randn(64, 160, device=device), 2)
     w1 = ops.pack_weight(torch.randn(64, 1, 160, device=device), "bf16x3", device)
-    tp = ops.head_pack_text(torch.randn(10, 64, device=device))
+    tp = ops.head_pack_text(torch.randn(10, 64, device=device), cin=160)
     with pytest.raises(RuntimeError, match="no kernel for 160 input channels"):
         ops.head_fused(x, w1, tp)
