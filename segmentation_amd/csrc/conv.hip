@@ -239,7 +239,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_split_kernel(ConvArgs
     for (int v = 0; v < A_V; ++v) {
       const int e = tid + v * NTHR;
       float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (ridx[v] >= 0 && !(a.dbg & 2))
+      if (ridx[v] >= 0)
         x = *reinterpret_cast<const float4*>(src + (int64_t)ridx[v] * ld + col + (e & 7) * 4);
       ra[v] = x;
     }
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_split_kernel(ConvArgs
       const int e = tid + v * NTHR;
       const int j = e / (T * 4), p = e % (T * 4);
       uint4 x = make_uint4(0, 0, 0, 0);
-      if (e < W_E && !(a.dbg & 4))
+      if (e < W_E)
         x = *reinterpret_cast<const uint4*>(
             wsplit + (((int64_t)k * a.cout + col_base + j) * nchunk + cc) * (T * 64) + p * 16);
       rw[v] = x;
@@ -305,10 +305,10 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_split_kernel(ConvArgs
       }
       const bool more = s + 1 < nstage;
       if (more) {
-        if (kn != k && !(a.dbg & 16)) load_idx(kn);
+        if (kn != k) load_idx(kn);
         issue(kn, ccn);
       }
-      if (((wmask >> kcur) & 1u) && !(a.dbg & 1)) {
+      if ((wmask >> kcur) & 1u) {
         const char* Ab = ldsb + (s & 1) * BUF + aoff;
         const char* Wb = ldsb + (s & 1) * BUF + T * A_PLANE + woff;
 #pragma unroll
@@ -333,7 +333,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_split_kernel(ConvArgs
           }
         }
       }
-      if (more && !(a.dbg & 8)) commit((s + 1) & 1);
+      if (more) commit((s + 1) & 1);
       __syncthreads();
       k = kn;
       cc = ccn;
@@ -440,12 +440,12 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvArgs& a) {
     const int zero = (int)(first ? a.zero0 : a.zero1);
 #pragma unroll
     for (int v = 0; v < A_V; ++v) {
-      const uint32_t row = (uint32_t)((a_id[v] < 0 || (a.dbg & 2)) ? zero : a_id[v]);
+      const uint32_t row = (uint32_t)(a_id[v] < 0 ? zero : a_id[v]);
       const char* g = src + ((uint64_t)row * rowb + a_p[v]);
-      if (a_on[v] && (!(a.dbg & 8) || a_id[v] >= 0 || lane < 8))
+      if (a_on[v])
         __builtin_amdgcn_global_load_lds(g, (lds_ptr_t)(buf + (v * NTHR + wave * 64) * 16), 16, 0, 0);
     }
-    const char* wsrc = wsplit + ((a.dbg & 4) ? 0 : ((uint64_t)ik * wk_stride + (uint32_t)icc * GRPB));
+    const char* wsrc = wsplit + ((uint64_t)ik * wk_stride + (uint32_t)icc * GRPB);
 #pragma unroll
     for (int v = 0; v < W_V; ++v)
       if (w_on[v])
@@ -525,7 +525,7 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvArgs& a) {
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if (issued < nstage) issue_next((u + NBUF - 1) % NBUF);
-        if (((wmask >> ck) & 1u) && !(a.dbg & 1)) compute(u);
+        if ((wmask >> ck) & 1u) compute(u);
         if (++ccc == nchunk) {
           ccc = 0;
           crem &= crem - 1;
@@ -534,7 +534,7 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvArgs& a) {
       }
     }
   }
-  if (a.slab || (a.dbg & 32)) {
+  if (a.slab) {
     conv_epilogue<NT>(a, acc, orow_s, tile_base, col_base, wm, wn, lane);
   } else {
     __syncthreads();  // every wave is done with the staging buffers; reuse them for the output tile
@@ -838,10 +838,6 @@ extern "C" size_t m3d_conv_workspace_bytes(int64_t n, int cout, int k) {
 // mode: 0 exact f32, 1/2 split-bf16 with in-kernel activation split (T = 2/3), 3/4 LDS-DMA on sf32 inputs (T = 2/3)
 static int run_conv(ConvArgs& a, int mode, bool mfma_ok, void* d_ws, size_t ws_bytes, hipStream_t stream,
                     const char* who) {
-  {
-    const char* e = getenv("M3D_DBG");
-    a.dbg = e ? atoi(e) : 0;
-  }
   a.slab = nullptr;
   if (!mfma_ok) {
     if (mode >= 3) {

@@ -20,7 +20,6 @@ struct ConvArgs {
   float* slab;  // split-K partial sums [z][npad][cout], or nullptr
   int64_t n, npad, ldo;
   int c0, c1, cout, kvol, relu;
-  int dbg;  // timing-only ablation bits (M3D_DBG); 0 in normal operation
   // split-format ("sf32") operands of the LDS-DMA kernel: [rows + 1][C/32][T][32] bf16, last row zero
   const char* s0;
   const char* s1;
