@@ -283,31 +283,34 @@ __global__ void sched_pattern_key_kernel(const int32_t* __restrict__ pair, int64
   vals[row] = (uint32_t)row;
 }
 
-__global__ __launch_bounds__(256) void sched_gather_kernel(const int32_t* __restrict__ pair, int64_t ld,
-                                                           int64_t n, int64_t npad,
-                                                           const uint32_t* __restrict__ order,
-                                                           int32_t* __restrict__ nbr,
-                                                           int32_t* __restrict__ out_row) {
-  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int k = blockIdx.y;
-  if (t >= npad) return;
-  const int32_t row = t < n ? (order ? (int32_t)order[t] : (int32_t)t) : -1;
-  if (k == 0) out_row[t] = row;
-  nbr[(int64_t)k * npad + t] = row >= 0 ? pair[(int64_t)k * ld + row] : -1;
-}
-
-// One wave per 64 schedule rows = two 32-row tiles.
-__global__ __launch_bounds__(256) void sched_mask_kernel(const int32_t* __restrict__ nbr, int kvol,
-                                                         int64_t npad, uint32_t* __restrict__ tile_mask) {
+// Schedule rows -> gathered kernel map, output rows and tile masks in one pass.  One wave per 64 schedule rows
+// (= two 32-row tiles); bit k of a tile's mask says that some row of the tile has a neighbour at offset k.
+__global__ __launch_bounds__(256) void sched_gather_mask_kernel(const int32_t* __restrict__ pair, int64_t ld,
+                                                                int64_t n, int64_t npad, int kvol,
+                                                                const uint32_t* __restrict__ order,
+                                                                int32_t* __restrict__ nbr,
+                                                                int32_t* __restrict__ out_row,
+                                                                uint32_t* __restrict__ tile_mask) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int64_t base = ((int64_t)blockIdx.x * 4 + wave) * 64;
   if (base >= npad) return;
+  const int64_t t = base + lane;
+  const int32_t row = t < n ? (order ? (int32_t)order[t] : (int32_t)t) : -1;
+  out_row[t] = row;
   uint32_t lo = 0, hi = 0;
-  for (int k = 0; k < kvol; ++k) {
-    const bool v = nbr[(int64_t)k * npad + base + lane] >= 0;
-    const uint64_t bal = __ballot(v);
-    if (bal & 0xFFFFFFFFull) lo |= 1u << k;
-    if (bal >> 32) hi |= 1u << k;
+  for (int k0 = 0; k0 < kvol; k0 += 9) {  // nine independent gathers in flight, then stores and votes
+    int32_t v[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) v[i] = (row >= 0 && k0 + i < kvol) ? pair[(int64_t)(k0 + i) * ld + row] : -1;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      if (k0 + i < kvol) {
+        nbr[(int64_t)(k0 + i) * npad + t] = v[i];
+        const uint64_t bal = __ballot(v[i] >= 0);
+        if (bal & 0xFFFFFFFFull) lo |= 1u << (k0 + i);
+        if (bal >> 32) hi |= 1u << (k0 + i);
+      }
+    }
   }
   if (lane == 0) {
     tile_mask[base / 32] = lo;
@@ -531,10 +534,8 @@ extern "C" int m3d_build_schedule(const int32_t* d_pair, int k, int64_t ld, int6
     order = in_alt ? valt : vals;
   }
   if (mode == 0 && d_base_order) order = reinterpret_cast<const uint32_t*>(d_base_order);
-  hipLaunchKernelGGL(sched_gather_kernel, dim3((unsigned)cdiv(npad, bs), k), dim3(bs), 0, stream, d_pair,
-                     ld, n, npad, order, d_nbr, d_out_row);
-  hipLaunchKernelGGL(sched_mask_kernel, dim3((unsigned)cdiv(npad, 256)), dim3(256), 0, stream, d_nbr, k,
-                     npad, d_tile_mask);
+  hipLaunchKernelGGL(sched_gather_mask_kernel, dim3((unsigned)cdiv(npad, 256)), dim3(256), 0, stream, d_pair, ld, n,
+                     npad, k, order, d_nbr, d_out_row, d_tile_mask);
   M3D_LAUNCH_CHECK();
   return M3D_OK;
 }
