@@ -241,25 +241,26 @@ __device__ __forceinline__ void head_fused_body(const HeadArgs& a) {
   };
 
   // Stage loop.  sync(k), once per stage and wave: tile k has landed for every wave, and every wave is done with
-  // tile k - 2, whose buffer then receives tile k + 1.  The lower half of the waves syncs between stages
+  // tile k - 2, whose buffer may then receive tile k + 1.  The lower half of the waves syncs between stages
   // (.. A(s) B(s) | A(s+1) ..), the upper half between the two products (.. A(s) | B(s) A(s+1) | ..): on every SIMD
   // one wave is in the MFMA-dense product B while its partner is in A (short dependent MFMA chain, VALU split) or
-  // issuing DMA.
-  auto sync = [&](int k) {
+  // issuing its share of the next tile's DMA - the lower half right after the barrier, the upper half after its B.
+  auto sync = [&]() {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if (k + 1 < nstage) issue(k + 1, (k + 1) % NBUF);
   };
   const bool rotated = NW == 8 && wave >= 4;
   issue(0, 0);
-  sync(0);
+  sync();
+  if (nstage > 1) issue(1, 1);
   for (int s = 0; s < nstage; ++s) {
     if (active) stage_a(s);
-    if (rotated) sync(s + 1);
+    if (rotated) sync();  // tile s + 1 has landed
     if (active) stage_b(s);
-    if (!rotated) sync(s + 1);
+    if (!rotated) sync();
+    if (s + 2 < nstage) issue(s + 2, (s + 2) % NBUF);
   }
   if (!active) return;
 
