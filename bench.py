@@ -196,7 +196,7 @@ def main():
                     variants=None if folded_ms is None else dict(
                         fold_head=dict(ms_per_step=folded_ms, voxels_per_s_this_rank=nvox / args.steps / (folded_ms * 1e-3),
                                        note="final 96->768 folded into the text matrix; labels identical in tests; "
-                                            "not the headline because the 768-d features are not materialised")))
+                                            "not the headline because the 768-d features are never formed")))
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

@@ -30,7 +30,8 @@ def _case(device, n, cin, cmid, ncls, seed, affine=True):
                                              (777, 128, 256, 128), (300, 32, 96, 129), (2000, 96, 768, 256),
                                              (513, 96, 512, 20), (700, 96, 768, 150), (640, 128, 1024, 256),
                                              (900, 64, 768, 200), (70000, 96, 768, 200),
-                                             (40000, 32, 64, 100)])
+                                             (40000, 32, 64, 100), (1, 96, 768, 200),
+                                             (31, 96, 32, 1), (33, 64, 32, 2)])
 def test_fused_head_matches_float64(device, n, cin, cmid, ncls):
     c = _case(device, n, cin, cmid, ncls, seed=n)
     xs = ops.split_f32(c["x"], 2)
