@@ -292,21 +292,22 @@ class SparseConvolution(SparseModule):
 class _SparseConvFn(torch.autograd.Function):
     """out = conv(feats, weight) + bias through m3d_conv_fwd_f32; the input gradient is the forward kernel on the
     transposed weights over the transposed kernel map (for a submanifold map: the same schedule with the kernel
-    offsets reversed), the weight gradient is m3d_conv_bwd_weight_f32."""
+    offsets reversed), the weight gradient is m3d_conv_bwd_weight_f32 (always exact f32 products).  Forward and
+    input gradient form their products as set_precision() says (f32 activations are split inside the kernel)."""
 
     @staticmethod
     def forward(ctx, feats, weight, bias, sched_fwd, sched_back, n_out, n_in, flip):
         feats = feats.contiguous()
-        w = ops.pack_weight(weight.detach(), "f32")
+        w = ops.pack_weight(weight.detach(), _PRECISION)
         out = ops.conv_fwd(feats, w, sched_fwd, n_out, shift=None if bias is None else bias.detach().float().contiguous())
         ctx.save_for_backward(feats, weight)
-        ctx.meta = (sched_fwd, sched_back, n_out, n_in, flip, bias is not None)
+        ctx.meta = (sched_fwd, sched_back, n_out, n_in, flip, bias is not None, _PRECISION)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         feats, weight = ctx.saved_tensors
-        sched_fwd, sched_back, n_out, n_in, flip, has_bias = ctx.meta
+        sched_fwd, sched_back, n_out, n_in, flip, has_bias, precision = ctx.meta
         dout = dout.contiguous().float()
         cout, cin = weight.shape[0], weight.shape[-1]
         k = weight.numel() // (cout * cin)
@@ -315,7 +316,7 @@ class _SparseConvFn(torch.autograd.Function):
             wt = weight.detach().reshape(cout, k, cin).permute(2, 1, 0)  # [Cin, k, Cout]
             if flip:
                 wt = wt.flip(1)
-            dx = ops.conv_fwd(dout, ops.pack_weight(wt.contiguous(), "f32"), sched_back, n_in)
+            dx = ops.conv_fwd(dout, ops.pack_weight(wt.contiguous(), precision), sched_back, n_in)
         if ctx.needs_input_grad[1]:
             dw = ops.conv_bwd_weight(feats, dout, sched_fwd, k).reshape(weight.shape)
         if has_bias and ctx.needs_input_grad[2]:

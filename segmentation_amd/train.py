@@ -20,6 +20,12 @@ def unique_text_features(embeddings: Sequence[Sequence[torch.Tensor]]):
     """extract_text_features with precomputed embeddings (caption_loss.py:30-39): unique rows of the stacked
     caption embeddings (np.unique along axis 0) -> (text_features [U,D], labels_per_segment [S], labels_per_caption [U])."""
     text = torch.stack([item for sub in embeddings for item in sub], 0)
+    if text.is_cuda:  # same result (rows in lexicographic order, first occurrences) without leaving the device
+        uniq, inverse = torch.unique(text.detach(), dim=0, return_inverse=True)
+        s = text.shape[0]
+        first = torch.full((uniq.shape[0],), s, dtype=torch.int64, device=text.device)
+        first.scatter_reduce_(0, inverse, torch.arange(s, device=text.device), reduce="amin")
+        return text[first], inverse, first
     device = text.device
     _, first, inverse = np.unique(text.detach().cpu().numpy(), return_index=True, return_inverse=True, axis=0)
     first = torch.from_numpy(first).to(device)
@@ -28,8 +34,13 @@ def unique_text_features(embeddings: Sequence[Sequence[torch.Tensor]]):
 
 def caption_loss(point_features, text_features, labels_per_segment, point_indices, caption_offsets,
                  num_points_per_caption, normalize: bool = True, logit_scale: Optional[torch.Tensor] = None,
-                 reduction: str = "weighted_sum"):
-    """CaptionLoss.loss after the text features are known (caption_loss.py:212-235)."""
+                 reduction: str = "weighted_sum", row_map: Optional[torch.Tensor] = None):
+    """CaptionLoss.loss after the text features are known (caption_loss.py:212-235).
+
+    row_map: when the per-point features are a row gather of fewer distinct rows (clip_feat = features[v2p_map],
+    language_module.py:205), pass the distinct rows as `point_features` and the gather index as `row_map`:
+    normalisation, logits and log-softmax are row-wise and commute with the gather, so they run once per voxel
+    instead of once per point, and the [N_points, D] tensor is never formed."""
     device = point_features.device
     if normalize:
         point_features = F.normalize(point_features, dim=-1)
@@ -37,7 +48,7 @@ def caption_loss(point_features, text_features, labels_per_segment, point_indice
     if logit_scale is not None:
         logits = logit_scale.exp() * logits
     scores = F.log_softmax(logits, dim=-1)
-    rep = scores[point_indices]
+    rep = scores[point_indices if row_map is None else row_map[point_indices]]
     reduced = segment_csr(rep, caption_offsets.to(device), reduce="mean")
     loss = F.nll_loss(reduced, labels_per_segment.to(device), reduction="none")
     if reduction == "mean":
@@ -114,11 +125,11 @@ class TrainStep:
         out = self.model(batch)
         feats = out["sparse_conv_feat"].features if isinstance(out, dict) else out.sparse_conv_feat.features
         v2p = out["v2p_map"] if isinstance(out, dict) else out.v2p_map
-        clip_feat = feats[v2p]  # language_module.py:205
         cd = batch["caption_data"]
         text, seg_labels, _ = unique_text_features(cd["embedding"])
-        return caption_loss(clip_feat, text, seg_labels, cd["point_indices"], cd["caption_offsets"],
-                            cd["num_points_per_caption"], logit_scale=self.logit_scale)
+        # clip_feat = feats[v2p] (language_module.py:205) is applied inside the loss as a row map
+        return caption_loss(feats, text, seg_labels, cd["point_indices"], cd["caption_offsets"],
+                            cd["num_points_per_caption"], logit_scale=self.logit_scale, row_map=v2p)
 
     def __call__(self, batch: Dict) -> float:
         self.model.train()

@@ -126,6 +126,27 @@ def test_caption_loss_matches_a_direct_restatement(device):
     assert _rel(fg.grad, fr.grad) < 1e-4
 
 
+def test_caption_loss_row_map_equals_gathered_rows(device):
+    """clip_feat = features[v2p_map] applied inside the loss (once per voxel) equals the per-point form."""
+    rng = np.random.default_rng(1)
+    n_vox, n_pts, d = 1500, 5000, 64
+    vf = torch.from_numpy(rng.normal(size=(n_vox, d)).astype(np.float32)).to(device)
+    v2p = torch.from_numpy(rng.integers(0, n_vox, size=n_pts)).to(device)
+    cd = _caption_batch(rng, n_pts, 10, d, device)
+    text, seg, first = train.unique_text_features(cd["embedding"])
+    stacked = torch.stack(cd["embedding"][0])
+    assert torch.equal(text[seg], stacked) and torch.equal(stacked[first], text)  # unique rows, first occurrences
+    a = vf.clone().requires_grad_(True)
+    la = train.caption_loss(a[v2p], text, seg, cd["point_indices"], cd["caption_offsets"], cd["num_points_per_caption"])
+    la.backward()
+    b = vf.clone().requires_grad_(True)
+    lb = train.caption_loss(b, text, seg, cd["point_indices"], cd["caption_offsets"], cd["num_points_per_caption"],
+                            row_map=v2p)
+    lb.backward()
+    assert abs(la.item() - lb.item()) <= 1e-6 * abs(la.item())
+    assert _rel(b.grad, a.grad.cpu()) < 1e-5
+
+
 class _CpuConvs:
     """Runs a model built on sparse.py's modules on the CPU: voxelisation and every sparse convolution go
     through the oracle (float64, torch autograd)."""

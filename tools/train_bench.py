@@ -1,14 +1,17 @@
 """Training step timing (the training benchmark case): B scenes per GPU, spunet34c+ppt, 300 captions per scene with
 random point subsets and random unit text rows, fwd + bwd + gradient all-reduce + SGD.
-usage: python tools/train_bench.py [scenes_per_gpu] [target_voxels] [steps]   (torchrun for several ranks)"""
+usage: python tools/train_bench.py [scenes_per_gpu] [target_voxels] [steps] [precision]   (torchrun for several ranks)
+precision: how forward and input-gradient convolutions form their products (f32 | bf16x3 | bf16x6; default bf16x3)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from segmentation_amd import ops, scenes, spunet, train
+from segmentation_amd import ops, scenes, sparse, spunet, train
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 TV = int(sys.argv[2]) if len(sys.argv) > 2 else 100000
 STEPS = int(sys.argv[3]) if len(sys.argv) > 3 else 5
+PREC = sys.argv[4] if len(sys.argv) > 4 else "bf16x3"
+sparse.set_precision(PREC)
 rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
 dist = None
 if world > 1:
@@ -44,7 +47,7 @@ dt = (time.perf_counter() - t0) / STEPS
 with torch.no_grad():
     nvox = ops.voxelize(batch["coord"], batch["feat"], batch["offset"], 0.02)["n_voxels"]
 if rank == 0:
-    print(f"train step: {B} scenes/GPU x {world} GPU, {nvox} voxels/GPU, {batch['coord'].shape[0]} points/GPU: {dt * 1e3:.1f} ms/step, "
+    print(f"train step [{PREC}]: {B} scenes/GPU x {world} GPU, {nvox} voxels/GPU, {batch['coord'].shape[0]} points/GPU: {dt * 1e3:.1f} ms/step, "
           f"{nvox * world / dt / 1e6:.2f} M voxels/s, loss {loss:.4f}, peak mem {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
 if dist is not None:
     dist.destroy_process_group()
