@@ -45,21 +45,26 @@ __global__ void subm_insert_kernel(const int4* __restrict__ idx, int64_t n, Shap
   }
 }
 
+// Offsets k and 26 - k are opposite: if voxel r sits at offset k of voxel j, then j sits at offset 26 - k of r.
+// Only k = 0 .. 12 are probed in the hash table; a hit also fills the mirrored entry (each entry has exactly one
+// writer), the misses of the upper half are the -1 the caller pre-filled it with.  k = 13 is the voxel itself.
 __global__ __launch_bounds__(256) void subm_probe_kernel(const int4* __restrict__ idx, int64_t n,
                                                          Shape3 sh, HashTable tab,
                                                          int32_t* __restrict__ pair) {
   const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int k = blockIdx.y;
+  const int k = blockIdx.y;  // 0 .. 13
   if (j >= n) return;
+  if (k == 13) {
+    pair[(int64_t)13 * n + j] = (int32_t)j;
+    return;
+  }
   const int4 c = idx[j];
   const int x = c.y + (k / 9) - 1, y = c.z + ((k / 3) % 3) - 1, z = c.w + (k % 3) - 1;
   int32_t r = -1;
-  if (k == 13) {
-    r = (int32_t)j;
-  } else if (x >= 0 && y >= 0 && z >= 0 && x < sh.s[0] && y < sh.s[1] && z < sh.s[2]) {
+  if (x >= 0 && y >= 0 && z >= 0 && x < sh.s[0] && y < sh.s[1] && z < sh.s[2])
     r = table_find(tab, lin_key(c.x, x, y, z, sh));
-  }
   pair[(int64_t)k * n + j] = r;
+  if (r >= 0) pair[(int64_t)(26 - k) * n + r] = (int32_t)j;
 }
 
 // ------------------------------------------------------------------------------ strided k2 s2
@@ -361,7 +366,8 @@ extern "C" int m3d_subm_rulebook(const int32_t* d_indices, int64_t n, const int6
   hipLaunchKernelGGL(subm_insert_kernel, dim3(gb), dim3(bs), 0, stream, idx, n, sh, tkeys, tvals,
                      cap - 1);
   HashTable tab{tkeys, tvals, cap - 1};
-  hipLaunchKernelGGL(subm_probe_kernel, dim3(gb, 27), dim3(bs), 0, stream, idx, n, sh, tab, d_pair);
+  M3D_HIP(hipMemsetAsync(d_pair + (int64_t)14 * n, 0xFF, (size_t)13 * n * sizeof(int32_t), stream));
+  hipLaunchKernelGGL(subm_probe_kernel, dim3(gb, 14), dim3(bs), 0, stream, idx, n, sh, tab, d_pair);
   M3D_LAUNCH_CHECK();
   return M3D_OK;
 }

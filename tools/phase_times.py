@@ -1,4 +1,4 @@
-"""Wall-clock split of one step: voxelize / kernel maps / network+head (each synchronised)."""
+"""Wall-clock split of one step: voxelize / kernel maps / backbone / last layer + head (each synchronised)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -20,11 +20,15 @@ with torch.no_grad():
         sync(); t0 = time.perf_counter()
         vox = ops.voxelize(coord, feat, off, 0.02, pad=128); sync(); t1 = time.perf_counter()
         levels = eng.build_levels(vox["voxel_coords"], vox["spatial_shape"], vox["batch_size"]); sync(); t2 = time.perf_counter()
-        x = eng.backbone(vox["voxel_feats"], levels)
-        pair = eng._conv(eng.final, x, None, levels[0].n, need_f32=True, need_sf=eng._terms != 0); sync(); t3 = time.perf_counter()
-        src = pair[1] if eng._terms else pair[0]
-        logits = ops.conv_fwd(src, eng.text.w, None, levels[0].n)
-        vl = ops.argmax_rows(logits, eng.n_classes); pl = ops.gather_labels(vl, vox["v2p_map"]); sync(); t4 = time.perf_counter()
+        x = eng.backbone(vox["voxel_feats"], levels); sync(); t3 = time.perf_counter()
+        if eng.text_fused is not None:   # last layer + logits + argmax in one kernel
+            vl, _ = ops.head_fused(x[1], eng.final.w, eng.text_fused, scale=eng.final.scale, shift=eng.final.shift)
+        else:
+            pair = eng._conv(eng.final, x, None, levels[0].n, need_f32=True, need_sf=eng._terms != 0)
+            src = pair[1] if eng._terms else pair[0]
+            logits = ops.conv_fwd(src, eng.text.w, None, levels[0].n)
+            vl = ops.argmax_rows(logits, eng.n_classes)
+        pl = ops.gather_labels(vl, vox["v2p_map"]); sync(); t4 = time.perf_counter()
         T["vox"] += t1 - t0; T["maps"] += t2 - t1; T["net"] += t3 - t2; T["head"] += t4 - t3
         sync(); t5 = time.perf_counter(); eng.predict(coord, feat, off, 0.02); sync(); T["total"] += time.perf_counter() - t5
     print({k: round(v / R * 1e3, 3) for k, v in T.items()}, "ms")
