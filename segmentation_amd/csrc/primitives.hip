@@ -186,8 +186,11 @@ __global__ void unique_insert_kernel(const uint64_t* __restrict__ keys, int64_t 
   const uint64_t key = keys[i];
   uint64_t s = mix64(key) & mask;
   while (true) {
-    const uint64_t old = atomicCAS((unsigned long long*)&tkeys[s], (unsigned long long)kEmptyKey,
-                                   (unsigned long long)key);
+    // Most points repeat a key that is already in the table: look before the atomic.  A slot never changes once
+    // it holds a key, so a stale read can only show "empty", which the compare-and-swap then settles.
+    uint64_t old = *reinterpret_cast<const volatile uint64_t*>(&tkeys[s]);
+    if (old == kEmptyKey)
+      old = atomicCAS((unsigned long long*)&tkeys[s], (unsigned long long)kEmptyKey, (unsigned long long)key);
     if (old == kEmptyKey) {
       trep[s] = (int32_t)i;
       const int pos = atomicAdd(d_count, 1);
