@@ -372,7 +372,7 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvArgs& a) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
-  const int64_t tile_base = xcd_tile(blockIdx.x, gridDim.x) * BM;
+  const int64_t tile_base = (BM == 128 && a.tile_order ? (int64_t)a.tile_order[blockIdx.x] : xcd_tile(blockIdx.x, gridDim.x)) * BM;
   const int col_base = blockIdx.y * BN;
   const int nchunk = (a.c0 + a.c1) / kBK;
   const int g0 = a.c0 / kBK;
@@ -967,7 +967,7 @@ extern "C" int m3d_conv_fwd_f32(const float* d_in0, int c0, const float* d_in1, 
 extern "C" int m3d_conv_fwd_sf32(const void* d_in0, int c0, int64_t rows0, const void* d_in1, int c1,
                                  int64_t rows1, const void* d_weight, int k, int cout,
                                  const int32_t* d_nbr, const int32_t* d_out_row,
-                                 const uint32_t* d_tile_mask, int64_t n, int64_t npad,
+                                 const uint32_t* d_tile_mask, int64_t n, int64_t npad, const int32_t* d_tile_order,
                                  const int32_t* d_halo_cnt, const int32_t* d_halo_rows, const uint16_t* d_halo_loc,
                                  const int32_t* d_halo_order, const float* d_scale, const float* d_shift, const float* d_residual,
                                  int relu, float* d_out, int64_t ldo, void* d_out_split, int terms,
@@ -999,6 +999,7 @@ extern "C" int m3d_conv_fwd_sf32(const void* d_in0, int c0, int64_t rows0, const
                   who, m3d_halo_tile_rows());
     return run_conv_halo(a, d_halo_cnt, d_halo_rows, d_halo_loc, d_halo_order, stream);
   }
+  a.tile_order = d_tile_order;
   return run_conv(a, terms == 2 ? 3 : 4, true, d_ws, ws_bytes, stream, who);
 }
 

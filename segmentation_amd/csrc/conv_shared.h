@@ -26,6 +26,7 @@ struct ConvArgs {
   int64_t zero0, zero1;  // index of the all-zero row of s0 / s1
   char* out_split;       // optional sf32 copy of the output (cout/32 groups per row)
   int terms;             // T of out_split
+  const int32_t* tile_order;  // optional: tile taken by workgroup blockIdx.x of a 128-row-tile launch
 };
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));

@@ -323,6 +323,56 @@ __global__ __launch_bounds__(256) void sched_gather_mask_kernel(const int32_t* _
   }
 }
 
+// Heaviest-first order of the 128-row tiles: tiles sorted by their number of active kernel offsets, descending,
+// ties in schedule order (a stable counting sort over the 28 possible counts, one workgroup).  Workgroups are
+// dispatched in index order, so the tiles with the longest reductions start first and the light ones fill the
+// tail of the launch.
+__global__ __launch_bounds__(1024) void tile_order_kernel(const uint32_t* __restrict__ mask, int nt,
+                                                          int32_t* __restrict__ order) {
+  __shared__ int hist[28], base[28], wcnt[16][28];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  auto work_of = [&](int t) {
+    const uint4 m = *reinterpret_cast<const uint4*>(mask + 4 * (int64_t)t);
+    return __popc(m.x | m.y | m.z | m.w);
+  };
+  if (tid < 28) hist[tid] = 0;
+  __syncthreads();
+  for (int t = tid; t < nt; t += 1024) atomicAdd(&hist[work_of(t)], 1);
+  __syncthreads();
+  if (tid == 0) {
+    int run = 0;
+    for (int w = 27; w >= 0; --w) {
+      base[w] = run;
+      run += hist[w];
+    }
+  }
+  __syncthreads();
+  const uint64_t lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+  for (int c0 = 0; c0 < nt; c0 += 1024) {
+    const int t = c0 + tid;
+    const int w = t < nt ? work_of(t) : -1;
+    int rank = 0;
+    for (int b = 0; b < 28; ++b) {
+      const uint64_t bal = __ballot(w == b);
+      if (w == b) rank = __popcll(bal & lt);
+      if (lane == 0) wcnt[wave][b] = __popcll(bal);
+    }
+    __syncthreads();
+    if (w >= 0) {
+      int off = 0;
+      for (int v = 0; v < wave; ++v) off += wcnt[v][w];
+      order[base[w] + off + rank] = t;
+    }
+    __syncthreads();
+    if (tid < 28) {
+      int sum = 0;
+      for (int v = 0; v < 16; ++v) sum += wcnt[v][tid];
+      base[tid] += sum;
+    }
+    __syncthreads();
+  }
+}
+
 static inline uint64_t table_cap(int64_t n) { return next_pow2((uint64_t)(n > 0 ? n : 1) * 2); }
 
 }  // namespace m3d
@@ -542,6 +592,15 @@ extern "C" int m3d_build_schedule(const int32_t* d_pair, int k, int64_t ld, int6
   if (mode == 0 && d_base_order) order = reinterpret_cast<const uint32_t*>(d_base_order);
   hipLaunchKernelGGL(sched_gather_mask_kernel, dim3((unsigned)cdiv(npad, 256)), dim3(256), 0, stream, d_pair, ld, n,
                      npad, k, order, d_nbr, d_out_row, d_tile_mask);
+  M3D_LAUNCH_CHECK();
+  return M3D_OK;
+}
+
+extern "C" int m3d_schedule_tile_order(const uint32_t* d_tile_mask, int64_t npad, int32_t* d_tile_order, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  M3D_CHECK_ARG(d_tile_mask && d_tile_order, "m3d_schedule_tile_order: null pointer");
+  M3D_CHECK_ARG(npad > 0 && npad % 128 == 0 && npad / 128 < (int64_t)INT_MAX, "m3d_schedule_tile_order: npad must be a positive multiple of 128");
+  hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, stream, d_tile_mask, (int)(npad / 128), d_tile_order);
   M3D_LAUNCH_CHECK();
   return M3D_OK;
 }

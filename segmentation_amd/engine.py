@@ -76,6 +76,8 @@ class SpUNetEngine:
         # with a split precision `final` also writes an sf32 copy of the features for the logits GEMM
         self.head_precision = precision
         self.fuse_head = os.environ.get("M3D_FUSE_HEAD", "1") != "0"
+        # 128-row tiles of the submanifold convolutions are launched heaviest first (m3d_schedule_tile_order)
+        self.tile_order = os.environ.get("M3D_TILE_ORDER", "1") != "0"
         self.device = torch.device(device)
         self.channels, self.layers = tuple(cfg["channels"]), tuple(cfg["layers"])
         self.num_stages = len(self.layers) // 2
@@ -163,7 +165,8 @@ class SpUNetEngine:
             lv.pair_subm = ops.subm_rulebook(lv.indices, lv.shape)
             halo = l in self.halo_levels and self._terms == 2
             mode = self.halo_mode if halo else self.sched_modes[min(l, len(self.sched_modes) - 1)]
-            lv.subm = ops.build_schedule(lv.pair_subm, lv.n, lv.indices, mode, lv.shape, batch_size)
+            lv.subm = ops.build_schedule(lv.pair_subm, lv.n, lv.indices, mode, lv.shape, batch_size,
+                                         tile_order=self.tile_order and not halo)
             if halo:
                 ops.build_halo(lv.subm, lv.n)
             if lv.pair_fwd is not None:

@@ -176,6 +176,7 @@ class Schedule:
     npad: int
     k: int
     halo: object = None      # optional (cnt [npad/256] i32, rows [npad/256, 640] i32, loc [npad/256, k, 256] i16)
+    tile_order: object = None  # optional [npad/128] i32: 128-row tiles, heaviest first (m3d_schedule_tile_order)
 
 
 def build_halo(sched, n_in, order_by_schedule=True):
@@ -199,7 +200,8 @@ def build_halo(sched, n_in, order_by_schedule=True):
     return sched
 
 
-def build_schedule(pair, n, indices=None, mode=0, spatial_shape=None, batch_size=1, base_order=None):
+def build_schedule(pair, n, indices=None, mode=0, spatial_shape=None, batch_size=1, base_order=None,
+                   tile_order=False):
     lib = _lib.load()
     _need_cuda(pair)
     assert pair.dtype == torch.int32 and pair.dim() == 2
@@ -222,7 +224,12 @@ def build_schedule(pair, n, indices=None, mode=0, spatial_shape=None, batch_size
                                 _ptr(base_order), _ptr(nbr), _ptr(out_row), _ptr(mask), _ptr(ws), ws.numel(),
                                 _stream())
     _lib.check(rc, "m3d_build_schedule")
-    return Schedule(nbr, out_row, mask, n, npad, k)
+    sched = Schedule(nbr, out_row, mask, n, npad, k)
+    if tile_order:
+        sched.tile_order = torch.empty((npad // 128,), dtype=torch.int32, device=dev)
+        rc = lib.m3d_schedule_tile_order(_ptr(mask), npad, _ptr(sched.tile_order), _stream())
+        _lib.check(rc, "m3d_schedule_tile_order")
+    return sched
 
 
 # ----------------------------------------------------------------------------- convolution
@@ -368,7 +375,9 @@ def conv_fwd(in0, weight_packed: PackedWeight, sched: Optional[Schedule], n_out,
     if sf_in:
         rc = lib.m3d_conv_fwd_sf32(_ptr(in0.data), c0, in0.n, _ptr(None if in1 is None else in1.data), c1,
                                    0 if in1 is None else in1.n, _ptr(weight_packed.data), k, cout, _ptr(nbr),
-                                   _ptr(orow), _ptr(mask), n_out, npad, _ptr(hcnt), _ptr(hrows), _ptr(hloc), _ptr(horder),
+                                   _ptr(orow), _ptr(mask), n_out, npad,
+                                   _ptr(None if sched is None else sched.tile_order),
+                                   _ptr(hcnt), _ptr(hrows), _ptr(hloc), _ptr(horder),
                                    _ptr(scale), _ptr(shift), _ptr(residual),
                                    int(bool(relu)), _ptr(out), ldo, _ptr(osp), in0.terms,
                                    _ptr(ws), ws.numel(), _stream())

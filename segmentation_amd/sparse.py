@@ -73,7 +73,7 @@ class ImplicitGemmIndiceData:
             # Morton order (other kernel sizes); strided outputs are already in row-major spatial order
             mode = (3 if self.pair_fwd.shape[0] == 27 else 1) if self.is_subm else 0
             self._sched_fwd = ops.build_schedule(self.pair_fwd, n_out, self.out_indices if mode else None, mode,
-                                                 self.out_spatial_shape, self.batch_size)
+                                                 self.out_spatial_shape, self.batch_size, tile_order=mode == 3)
         return self._sched_fwd
 
     @property

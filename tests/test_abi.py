@@ -42,9 +42,10 @@ def test_argument_validation_without_gpu():
     rc = lib.m3d_conv_fwd_f32(null, 32, null, 0, null, 27, 32, null, null, null, 5, 128, null, null, null, 0, null, 32,
                               null, 0, 0, null, 0, null)
     assert rc == -1
-    rc = lib.m3d_conv_fwd_sf32(one := ctypes.c_void_p(8), 33, 5, null, 0, 0, one, 27, 32, null, null, null, 5, 128,
+    rc = lib.m3d_conv_fwd_sf32(one := ctypes.c_void_p(8), 33, 5, null, 0, 0, one, 27, 32, null, null, null, 5, 128, null,
                                null, null, null, null, null, null, null, 0, one, 32, null, 2, null, 0, null)
     assert rc == -1 and b"multiples of 32" in lib.m3d_last_error()
+    assert lib.m3d_schedule_tile_order(one, 100, one, null) == -1 and b"multiple of 128" in lib.m3d_last_error()
     assert lib.m3d_sf32_bytes(10, 64, 2) == 11 * 64 * 4
     shape = (ctypes.c_int64 * 3)(0, 4, 4)
     one = ctypes.c_void_p(8)  # never dereferenced: the shape check fails first

@@ -137,3 +137,30 @@ def test_avgpool_over_the_strided_map(device):
     assert ((out.cpu().double() - ref).abs().max() / ref.abs().max()).item() < 1e-6
     out2, none = fn(x[:, 0].to(device), pf, pf.shape[1], False)
     assert none is None and torch.allclose(out2.cpu(), out[:, 0].cpu())
+
+
+def test_tile_order_is_heaviest_first_and_changes_no_result(device):
+    """m3d_schedule_tile_order: a permutation of the 128-row tiles, sorted by active-offset count (descending,
+    ties in schedule order); a convolution run with it gives bit-identical output."""
+    sc = scenes.make_scene(seed=4, target_voxels=30000)
+    n = sc["coord"].shape[0]
+    sp = oracle.sparsify(sc["coord"], sc["feat"], np.array([0, n]), 0.02)
+    idx = torch.from_numpy(sp["voxel_coords"]).to(device)
+    pair = ops.subm_rulebook(idx, sp["spatial_shape"])
+    nv = idx.shape[0]
+    plain = ops.build_schedule(pair, nv, idx, 3 | (6 << 8), sp["spatial_shape"], 1)
+    sched = ops.build_schedule(pair, nv, idx, 3 | (6 << 8), sp["spatial_shape"], 1, tile_order=True)
+    assert torch.equal(plain.out_row, sched.out_row) and plain.tile_order is None
+    order = sched.tile_order.cpu().numpy()
+    nt = sched.npad // 128
+    assert order.shape == (nt,) and np.array_equal(np.sort(order), np.arange(nt))
+    m = sched.tile_mask.cpu().numpy().view(np.uint32).reshape(nt, 4)
+    u = m[:, 0] | m[:, 1] | m[:, 2] | m[:, 3]
+    work = np.array([bin(int(v)).count("1") for v in u])
+    expect = np.argsort(-work, kind="stable")
+    assert np.array_equal(order, expect)
+    x = ops.split_f32(torch.randn(nv, 96, device=device), 2)
+    w = ops.pack_weight(torch.randn(96, 27, 96) * 0.05, "bf16x3", device)
+    a = ops.conv_fwd(x, w, plain, nv)
+    b = ops.conv_fwd(x, w, sched, nv)
+    assert torch.equal(a, b)
