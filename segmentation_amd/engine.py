@@ -141,13 +141,25 @@ class SpUNetEngine:
         self.text_folded = _Conv(ops.pack_weight(wfold, self.precision), None, bfold.contiguous())
 
     # ------------------------------------------------------------------ kernel maps
+    def _subm_schedule(self, l, pair, n, indices, shape, batch_size):
+        halo = l in self.halo_levels and self._terms == 2
+        mode = self.halo_mode if halo else self.sched_modes[min(l, len(self.sched_modes) - 1)]
+        sched = ops.build_schedule(pair, n, indices, mode, shape, batch_size, tile_order=self.tile_order and not halo)
+        if halo:
+            ops.build_halo(sched, n)
+        return sched
+
     def build_levels(self, voxel_coords, spatial_shape, batch_size=1):
         """Kernel maps + tile schedules of every resolution level.  The chain of strided maps runs first, with the
-        row counts handed from level to level on the device and read back once; the submanifold maps and all
-        schedules are enqueued afterwards without any host read-back, so the host runs ahead of the GPU into
-        the network."""
+        row counts handed from level to level on the device and read back once (behind the level-0 map work); the
+        submanifold maps and all schedules are enqueued without any further host read-back, so the host runs ahead
+        of the GPU into the network."""
         levels = []
-        chain = ops.strided_chain(voxel_coords, spatial_shape, batch_size, self.num_stages)
+        chain_done = ops.strided_chain(voxel_coords, spatial_shape, batch_size, self.num_stages, defer=True)
+        # level 0 needs nothing from the chain: its map and schedule keep the GPU busy while the counts travel
+        pair0 = ops.subm_rulebook(voxel_coords, list(spatial_shape))
+        sched0 = self._subm_schedule(0, pair0, voxel_coords.shape[0], voxel_coords, list(spatial_shape), batch_size)
+        chain = chain_done()
         idx, shape = voxel_coords, list(spatial_shape)
         for l in range(self.num_stages + 1):
             lv = _Level()
@@ -162,13 +174,11 @@ class SpUNetEngine:
             levels.append(lv)
             idx, shape = lv.next_indices, lv.next_shape
         for l, lv in enumerate(levels):
-            lv.pair_subm = ops.subm_rulebook(lv.indices, lv.shape)
-            halo = l in self.halo_levels and self._terms == 2
-            mode = self.halo_mode if halo else self.sched_modes[min(l, len(self.sched_modes) - 1)]
-            lv.subm = ops.build_schedule(lv.pair_subm, lv.n, lv.indices, mode, lv.shape, batch_size,
-                                         tile_order=self.tile_order and not halo)
-            if halo:
-                ops.build_halo(lv.subm, lv.n)
+            if l == 0:
+                lv.pair_subm, lv.subm = pair0, sched0
+            else:
+                lv.pair_subm = ops.subm_rulebook(lv.indices, lv.shape)
+                lv.subm = self._subm_schedule(l, lv.pair_subm, lv.n, lv.indices, lv.shape, batch_size)
             if lv.pair_fwd is not None:
                 lv.down = ops.build_schedule(lv.pair_fwd, lv.n_next, None, 0)
                 lv.up = ops.build_schedule(lv.pair_bwd, lv.n, None, 2, base_order=lv.subm.out_row)

@@ -123,11 +123,16 @@ def subm_rulebook(indices, spatial_shape):
     return pair
 
 
-def strided_chain(indices, spatial_shape, batch_size, depth):
+_PINNED_COUNTS = {}
+
+
+def strided_chain(indices, spatial_shape, batch_size, depth, defer=False):
     """`depth` successive k2 s2 p0 kernel maps (v1m3:154-161), each on the previous one's outputs.  The
     output count of a level stays on the device and feeds the next level, so the whole chain is enqueued
     without a host read-back; the counts are read once at the end.  Returns a list of
-    (out_indices [M,4], out_shape, pair_fwd [8,M] (a strided view), pair_bwd [8,N])."""
+    (out_indices [M,4], out_shape, pair_fwd [8,M] (a strided view), pair_bwd [8,N]).
+    With defer=True the counts travel to pinned host memory asynchronously and a function is returned that
+    waits for that copy alone and yields the list: work enqueued in between keeps the GPU busy meanwhile."""
     lib = _lib.load()
     _need_cuda(indices)
     indices = indices.contiguous()
@@ -150,14 +155,29 @@ def strided_chain(indices, spatial_shape, batch_size, depth):
         shape = [s // 2 for s in shape]
         bufs.append((out_idx, list(shape), pf, pb))
         cur = out_idx
-    m = counts.cpu().tolist()  # the one host sync of the chain
-    out, n_in = [], n
-    for l, (out_idx, oshape, pf, pb) in enumerate(bufs):
-        if m[l] == 0:
-            raise ValueError(f"strided_rulebook: level {l} has no output voxel")
-        out.append((out_idx[:m[l]], oshape, pf[:, :m[l]], pb[:, :n_in]))
-        n_in = m[l]
-    return out
+    def slices(m):
+        out, n_in = [], n
+        for l, (out_idx, oshape, pf, pb) in enumerate(bufs):
+            if m[l] == 0:
+                raise ValueError(f"strided_rulebook: level {l} has no output voxel")
+            out.append((out_idx[:m[l]], oshape, pf[:, :m[l]], pb[:, :n_in]))
+            n_in = m[l]
+        return out
+
+    if not defer:
+        return slices(counts.cpu().tolist())  # the one host sync of the chain
+    pinned = _PINNED_COUNTS.get(depth)
+    if pinned is None:
+        pinned = _PINNED_COUNTS[depth] = torch.empty((depth,), dtype=torch.int64, pin_memory=True)
+    pinned.copy_(counts, non_blocking=True)
+    landed = torch.cuda.Event()
+    landed.record()
+
+    def finish():
+        landed.synchronize()
+        return slices(pinned.tolist())
+
+    return finish
 
 
 def strided_rulebook(indices, spatial_shape, batch_size):
