@@ -200,6 +200,7 @@ int m3d_schedule_tile_order(const uint32_t* d_tile_mask, int64_t npad, int32_t* 
  *   d_weight: the reference's [Cout,k0,k1,k2,Cin] f32 weight converted by m3d_conv_pack_weight for
  *        the same `precision` ([k,cout,cin] f32, or pre-split bf16 terms)
  *   d_nbr/d_out_row/d_tile_mask: from m3d_build_schedule; all three NULL = dense 1x1 (k = 1)
+ *   d_tile_order: NULL or m3d_schedule_tile_order's output for this schedule (launch order of 128-row tiles)
  *   d_scale/d_shift [cout] may be NULL (1 / 0); d_residual [n_out_rows,cout] may be NULL
  *   d_out [n_out_rows, ldo] (ldo >= cout, row stride in floats)
  *   n = number of real output rows; npad = schedule length
@@ -208,7 +209,7 @@ size_t m3d_conv_workspace_bytes(int64_t n, int cout, int k);
 int m3d_conv_fwd_f32(const float* d_in0, int c0, const float* d_in1, int c1,
                      const float* d_weight, int k, int cout, const int32_t* d_nbr,
                      const int32_t* d_out_row, const uint32_t* d_tile_mask, int64_t n,
-                     int64_t npad, const float* d_scale, const float* d_shift,
+                     int64_t npad, const int32_t* d_tile_order, const float* d_scale, const float* d_shift,
                      const float* d_residual, int relu, float* d_out, int64_t ldo,
                      void* d_out_split, int out_terms, int precision, void* d_ws, size_t ws_bytes,
                      void* stream);

@@ -37,7 +37,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_f32_kernel(ConvArgs a
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
-  const int64_t tile_base = xcd_tile(blockIdx.x, gridDim.x) * BM;
+  const int64_t tile_base = (BM == 128 && a.tile_order ? (int64_t)a.tile_order[blockIdx.x] : xcd_tile(blockIdx.x, gridDim.x)) * BM;
   const int col_base = blockIdx.y * BN;
   const int cin = a.c0 + a.c1;
   const int nchunk = cin / kBK;
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_split_kernel(ConvArgs
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
-  const int64_t tile_base = xcd_tile(blockIdx.x, gridDim.x) * BM;
+  const int64_t tile_base = (BM == 128 && a.tile_order ? (int64_t)a.tile_order[blockIdx.x] : xcd_tile(blockIdx.x, gridDim.x)) * BM;
   const int col_base = blockIdx.y * BN;
   const int cin = a.c0 + a.c1;
   const int nchunk = cin / kBK;
@@ -938,7 +938,7 @@ static int check_schedule(const int32_t* d_nbr, const int32_t* d_out_row, const 
 extern "C" int m3d_conv_fwd_f32(const float* d_in0, int c0, const float* d_in1, int c1,
                                 const float* d_weight, int k, int cout, const int32_t* d_nbr,
                                 const int32_t* d_out_row, const uint32_t* d_tile_mask, int64_t n,
-                                int64_t npad, const float* d_scale, const float* d_shift,
+                                int64_t npad, const int32_t* d_tile_order, const float* d_scale, const float* d_shift,
                                 const float* d_residual, int relu, float* d_out, int64_t ldo,
                                 void* d_out_split, int out_terms, int precision, void* d_ws,
                                 size_t ws_bytes, void* stream_) {
@@ -960,6 +960,7 @@ extern "C" int m3d_conv_fwd_f32(const float* d_in0, int c0, const float* d_in1, 
   a.out = d_out; a.n = n; a.npad = npad; a.ldo = ldo; a.c0 = c0; a.c1 = c1;
   a.cout = cout; a.kvol = k; a.relu = relu;
   a.out_split = static_cast<char*>(d_out_split); a.terms = out_terms;
+  a.tile_order = d_tile_order;
   const bool mfma_ok = (c0 % 32 == 0) && (c1 % 32 == 0) && (cout % 32 == 0);
   return run_conv(a, precision, mfma_ok, d_ws, ws_bytes, stream, who);
 }
