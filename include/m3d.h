@@ -177,10 +177,12 @@ int m3d_build_schedule(const int32_t* d_pair, int k, int64_t ld, int64_t n,
                        int mode, const int32_t* d_base_order, int32_t* d_nbr, int32_t* d_out_row,
                        uint32_t* d_tile_mask, void* d_ws, size_t ws_bytes, void* stream);
 
-/* Optional companion of a schedule: the order in which a launch with 128-row tiles takes them, heaviest (most
- * active kernel offsets) first, ties in schedule order.  Workgroups start in index order, so the long reductions
- * go first and the short ones fill the tail of the launch (measured -12 % / -23 % on the 3x3x3 convolutions of the
- * two largest levels).  m3d_conv_fwd_sf32 applies it where its plan uses 128-row tiles and ignores it elsewhere.
+/* Optional companion of a schedule: the order in which a launch with 128-row tiles takes them.  The tiles are
+ * split into three classes by their number of active kernel offsets (the thirds of this schedule's tiles); the
+ * heaviest class goes first, schedule order inside a class.  Workgroups start in index order, so the long
+ * reductions go first and the short ones fill the tail of the launch (measured -12 % / -20 % on the 3x3x3
+ * convolutions of the two largest levels, for more HBM fetches: spatial neighbours no longer run side by side).
+ * Both convolution entry points apply it where their plan uses 128-row tiles and ignore it elsewhere.
  *   d_tile_mask [npad/32] from m3d_build_schedule;  d_tile_order [npad/128] i32 (a permutation of 0 .. npad/128-1)
  * No counterpart in the reference. */
 int m3d_schedule_tile_order(const uint32_t* d_tile_mask, int64_t npad, int32_t* d_tile_order, void* stream);

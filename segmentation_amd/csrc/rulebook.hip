@@ -323,13 +323,14 @@ __global__ __launch_bounds__(256) void sched_gather_mask_kernel(const int32_t* _
   }
 }
 
-// Heaviest-first order of the 128-row tiles: tiles sorted by their number of active kernel offsets, descending,
-// ties in schedule order (a stable counting sort over the 28 possible counts, one workgroup).  Workgroups are
-// dispatched in index order, so the tiles with the longest reductions start first and the light ones fill the
-// tail of the launch.
+// Launch order of the 128-row tiles: three classes by the number of active kernel offsets (the thirds of this
+// schedule's tiles, heaviest third first), schedule order inside a class - a stable counting sort, one workgroup.
+// Workgroups are dispatched in index order, so the tiles with the longest reductions start first and the light
+// ones fill the tail of the launch; a few coarse classes keep long runs of spatially adjacent tiles together and
+// measured as fast as a full sort by offset count.
 __global__ __launch_bounds__(1024) void tile_order_kernel(const uint32_t* __restrict__ mask, int nt,
                                                           int32_t* __restrict__ order) {
-  __shared__ int hist[28], base[28], wcnt[16][28];
+  __shared__ int hist[28], cls[28], base[3], wcnt[16][3];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   auto work_of = [&](int t) {
     const uint4 m = *reinterpret_cast<const uint4*>(mask + 4 * (int64_t)t);
@@ -340,31 +341,39 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(const uint32_t* __rest
   for (int t = tid; t < nt; t += 1024) atomicAdd(&hist[work_of(t)], 1);
   __syncthreads();
   if (tid == 0) {
-    int run = 0;
+    // offset counts from 27 down: class 0 until a third of the tiles is covered, class 1 until two thirds, then 2
+    int seen = 0, n0 = 0, n1 = 0;
     for (int w = 27; w >= 0; --w) {
-      base[w] = run;
-      run += hist[w];
+      const int c = 3 * seen < nt ? 0 : (3 * seen < 2 * nt ? 1 : 2);
+      cls[w] = c;
+      seen += hist[w];
+      if (c == 0) n0 += hist[w];
+      if (c == 1) n1 += hist[w];
     }
+    base[0] = 0;
+    base[1] = n0;
+    base[2] = n0 + n1;
   }
   __syncthreads();
   const uint64_t lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
   for (int c0 = 0; c0 < nt; c0 += 1024) {
     const int t = c0 + tid;
-    const int w = t < nt ? work_of(t) : -1;
+    const int c = t < nt ? cls[work_of(t)] : -1;
     int rank = 0;
-    for (int b = 0; b < 28; ++b) {
-      const uint64_t bal = __ballot(w == b);
-      if (w == b) rank = __popcll(bal & lt);
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      const uint64_t bal = __ballot(c == b);
+      if (c == b) rank = __popcll(bal & lt);
       if (lane == 0) wcnt[wave][b] = __popcll(bal);
     }
     __syncthreads();
-    if (w >= 0) {
+    if (c >= 0) {
       int off = 0;
-      for (int v = 0; v < wave; ++v) off += wcnt[v][w];
-      order[base[w] + off + rank] = t;
+      for (int v = 0; v < wave; ++v) off += wcnt[v][c];
+      order[base[c] + off + rank] = t;
     }
     __syncthreads();
-    if (tid < 28) {
+    if (tid < 3) {
       int sum = 0;
       for (int v = 0; v < 16; ++v) sum += wcnt[v][tid];
       base[tid] += sum;

@@ -140,8 +140,8 @@ def test_avgpool_over_the_strided_map(device):
 
 
 def test_tile_order_is_heaviest_first_and_changes_no_result(device):
-    """m3d_schedule_tile_order: a permutation of the 128-row tiles, sorted by active-offset count (descending,
-    ties in schedule order); a convolution run with it gives bit-identical output."""
+    """m3d_schedule_tile_order: a permutation of the 128-row tiles, three classes by active-offset count (thirds of
+    the tiles, heaviest first), schedule order inside a class; a convolution run with it gives bit-identical output."""
     sc = scenes.make_scene(seed=4, target_voxels=30000)
     n = sc["coord"].shape[0]
     sp = oracle.sparsify(sc["coord"], sc["feat"], np.array([0, n]), 0.02)
@@ -157,8 +157,14 @@ def test_tile_order_is_heaviest_first_and_changes_no_result(device):
     m = sched.tile_mask.cpu().numpy().view(np.uint32).reshape(nt, 4)
     u = m[:, 0] | m[:, 1] | m[:, 2] | m[:, 3]
     work = np.array([bin(int(v)).count("1") for v in u])
-    expect = np.argsort(-work, kind="stable")
+    hist = np.bincount(work, minlength=28)
+    cls, seen = np.zeros(28, int), 0
+    for wk in range(27, -1, -1):  # thirds of the tiles, heaviest offset counts first
+        cls[wk] = 0 if 3 * seen < nt else (1 if 3 * seen < 2 * nt else 2)
+        seen += hist[wk]
+    expect = np.argsort(cls[work], kind="stable")
     assert np.array_equal(order, expect)
+    assert work[order[: nt // 4]].mean() > work[order[-(nt // 4):]].mean()
     x = ops.split_f32(torch.randn(nv, 96, device=device), 2)
     w = ops.pack_weight(torch.randn(96, 27, 96) * 0.05, "bf16x3", device)
     a = ops.conv_fwd(x, w, plain, nv)
