@@ -201,10 +201,24 @@ __device__ __forceinline__ void head_fused_body(const HeadArgs& a) {
   bf16x8 ah[2], al[2];  // the current feature tile as A operand: [reduction half] hi / lo terms
 
   // A(s): F^T tile of features 32 s .. 32 s + 31 (features x rows), affine, split into ah / al
+  const bool has_scale = a.scale != nullptr;
   auto stage_a = [&](int s) {
+    // register r of f holds feature (r & 3) + 8 * (r >> 2) + 4 * h of the tile
+    const uint32_t ap = aff_lds + (uint32_t)(s * 32) * 4u;
     floatx16 f;
+    if (has_scale) {
 #pragma unroll
-    for (int j = 0; j < 16; ++j) f[j] = 0.f;
+      for (int j = 0; j < 16; ++j) f[j] = 0.f;
+    } else {  // shift only (a bias): the accumulator starts from it, nothing is left to do after the products
+      f32x4 sh[4];
+      lds_read16<kHeadMaxFeatures * 4>(sh[0], ap);
+      lds_read16<kHeadMaxFeatures * 4 + 32>(sh[1], ap);
+      lds_read16<kHeadMaxFeatures * 4 + 64>(sh[2], ap);
+      lds_read16<kHeadMaxFeatures * 4 + 96>(sh[3], ap);
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(sh[0]), "+v"(sh[1]), "+v"(sh[2]), "+v"(sh[3]));
+#pragma unroll
+      for (int j = 0; j < 16; ++j) f[j] = sh[j >> 2][j & 3];
+    }
     fragment_pipeline(std::integral_constant<int, 2 * G1>{}, std::integral_constant<int, 0>{},
                       lds_base + (uint32_t)((s % NBUF) * BUF), [&](auto ic, const bf16x8& wh, const bf16x8& wl) {
                         constexpr int i = decltype(ic)::value, g = i >> 1, ks = i & 1;
@@ -212,22 +226,24 @@ __device__ __forceinline__ void head_fused_body(const HeadArgs& a) {
                         f = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xf[g][ks][1], f, 0, 0, 0);
                         f = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xf[g][ks][0], f, 0, 0, 0);
                       });
-    // register r holds feature (r & 3) + 8 * (r >> 2) + 4 * h of the tile
-    const uint32_t ap = aff_lds + (uint32_t)(s * 32) * 4u;
-    static_for<0, 4>([&](auto qc) {
-      constexpr int q = decltype(qc)::value;
-      f32x4 sc, sh;
-      lds_read16<q * 32>(sc, ap);
-      lds_read16<kHeadMaxFeatures * 4 + q * 32>(sh, ap);
-      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(sc), "+v"(sh));
+    if (has_scale) {
+      static_for<0, 4>([&](auto qc) {
+        constexpr int q = decltype(qc)::value;
+        f32x4 sc, sh;
+        lds_read16<q * 32>(sc, ap);
+        lds_read16<kHeadMaxFeatures * 4 + q * 32>(sh, ap);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(sc), "+v"(sh));
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float v = f[4 * q + i] * sc[i] + sh[i];
-        const __bf16 hi = (__bf16)v;
-        ah[q >> 1][(q & 1) * 4 + i] = hi;
-        al[q >> 1][(q & 1) * 4 + i] = (__bf16)(v - (float)hi);
-      }
-    });
+        for (int i = 0; i < 4; ++i) f[4 * q + i] = f[4 * q + i] * sc[i] + sh[i];
+      });
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {  // split into the A operand of the second product
+      const float v = f[j];
+      const __bf16 hi = (__bf16)v;
+      ah[j >> 3][j & 7] = hi;
+      al[j >> 3][j & 7] = (__bf16)(v - (float)hi);
+    }
   };
   // B(s): logits += F tile . W2 tile s
   auto stage_b = [&](int s) {
