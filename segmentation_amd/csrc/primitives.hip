@@ -36,10 +36,15 @@ __global__ __launch_bounds__(kSortBlock) void radix_hist_kernel(
   if (chunk < nchunks) {
     const int64_t m = *d_count;
     const int64_t base = (int64_t)chunk * kWaveItems;
+    uint64_t kr[kRounds];
+#pragma unroll
     for (int r = 0; r < kRounds; ++r) {
-      int64_t i = base + r * 64 + lane;
-      if (i < m) atomicAdd(&h[wave][(keys[i] >> shift) & 255], 1u);
+      const int64_t i = base + r * 64 + lane;
+      kr[r] = i < m ? keys[i] : 0ull;
     }
+#pragma unroll
+    for (int r = 0; r < kRounds; ++r)
+      if (base + r * 64 + lane < m) atomicAdd(&h[wave][(kr[r] >> shift) & 255], 1u);
   }
   __syncthreads();
   if (chunk < nchunks)
@@ -84,36 +89,53 @@ __global__ __launch_bounds__(kSortBlock) void radix_scatter_kernel(
   __shared__ uint32_t base_s[256];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int chunk = blockIdx.x * (kSortBlock / 64) + wave;
-  {  // exclusive scan of the 256 digit totals (kSortBlock == 256 threads, one digit each)
-    const int t = threadIdx.x;
-    const uint32_t own = totals[t];
-    base_s[t] = own;
-    __syncthreads();
-    for (int off = 1; off < 256; off <<= 1) {
-      const uint32_t v = t >= off ? base_s[t - off] : 0;
-      __syncthreads();
-      base_s[t] += v;
-      __syncthreads();
+  // this wave's per-digit offsets are requested first; they land while the digit totals are scanned
+  uint32_t offs[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) offs[q] = chunk < nchunks ? offsets[(int64_t)(q * 64 + lane) * nchunks + chunk] : 0u;
+  const int64_t m = chunk < nchunks ? (int64_t)*d_count : 0;
+  const int64_t base = (int64_t)chunk * kWaveItems;
+  // all of the wave's elements are requested up front: the rounds below are serialised by the running offsets
+  // in LDS, and a load issued inside a round would add its full latency to every one of them
+  uint64_t keys_r[kRounds];
+  uint32_t vals_r[kRounds];
+#pragma unroll
+  for (int r = 0; r < kRounds; ++r) {
+    const int64_t i = base + r * 64 + lane;
+    keys_r[r] = i < m ? kin[i] : 0ull;
+    vals_r[r] = i < m ? vin[i] : 0u;
+  }
+  {  // exclusive scan of the 256 digit totals (kSortBlock == 256 threads, one digit each): shuffles inside a wave,
+     // one LDS round trip between the four waves
+    __shared__ uint32_t wsum[4];
+    const uint32_t own = totals[threadIdx.x];
+    uint32_t inc = own;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t t = __shfl_up(inc, d, 64);
+      if (lane >= d) inc += t;
     }
-    const uint32_t excl = base_s[t] - own;
+    if (lane == 63) wsum[wave] = inc;
     __syncthreads();
-    base_s[t] = excl;
+    uint32_t before = 0;
+    for (int w = 0; w < wave; ++w) before += wsum[w];
+    base_s[threadIdx.x] = before + inc - own;
     __syncthreads();
   }
-  if (chunk < nchunks)
-    for (int i = lane; i < 256; i += 64)
-      run_s[wave][i] = base_s[i] + offsets[(int64_t)i * nchunks + chunk];
+  if (chunk < nchunks) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) run_s[wave][q * 64 + lane] = base_s[q * 64 + lane] + offs[q];
+  }
   __syncthreads();
   if (chunk >= nchunks) return;
   volatile uint32_t* run = run_s[wave];
-  const int64_t m = *d_count;
-  const int64_t base = (int64_t)chunk * kWaveItems;
   const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
   for (int r = 0; r < kRounds; ++r) {
     const int64_t i = base + r * 64 + lane;
     const bool valid = i < m;
-    const uint64_t key = valid ? kin[i] : 0ull;
-    const uint32_t val = valid ? vin[i] : 0u;
+    const uint64_t key = keys_r[r];
+    const uint32_t val = vals_r[r];
     const unsigned d = (unsigned)(key >> shift) & 255u;
     uint64_t peers = __ballot(valid);
 #pragma unroll

@@ -123,18 +123,38 @@ __global__ void strided_outidx_kernel(const uint64_t* __restrict__ ukeys, const 
 // because output rows are ordered by ascending linear index.  No hashing, no sorting.
 constexpr int kBitmapBlockWords = 1024;  // words per 256-thread block (4 per thread)
 
-__global__ void strided_mark_kernel(const int4* __restrict__ idx, int64_t n, const int64_t* __restrict__ d_n,
-                                    Shape3 out_sh, uint64_t cells, unsigned long long* __restrict__ bitmap) {
+// Below level 0 the voxels come in ascending linear order, so the lanes of a wave hit runs of the same bitmap word,
+// and atomics on one address are served one at a time: equal words in neighbouring lanes are OR-ed together by a
+// segmented shuffle reduction first and only the first lane of each run touches memory.
+__global__ __launch_bounds__(256) void strided_mark_kernel(const int4* __restrict__ idx, int64_t n,
+                                                           const int64_t* __restrict__ d_n, Shape3 out_sh,
+                                                           uint64_t cells, unsigned long long* __restrict__ bitmap) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n || (d_n && i >= *d_n)) return;
-  const int4 c = idx[i];
-  const int x = c.y >> 1, y = c.z >> 1, z = c.w >> 1;
-  if (x >= out_sh.s[0] || y >= out_sh.s[1] || z >= out_sh.s[2]) return;
-  const uint64_t key = lin_key(c.x, x, y, z, out_sh);
-  if (key >= cells) return;  // batch index or coordinate out of range: never touch memory past the bitmap
-  const unsigned long long bit = 1ull << (key & 63);
-  // up to 8 children share a cell: most find the bit already set and skip the atomic
-  if (!(__builtin_nontemporal_load(&bitmap[key >> 6]) & bit)) atomicOr(&bitmap[key >> 6], bit);
+  const int lane = threadIdx.x & 63;
+  // no early return: every lane takes part in the shuffles (an inactive lane carries word -1, bits 0)
+  long long word = -1;
+  unsigned long long bits = 0;
+  if (i < n && !(d_n && i >= *d_n)) {
+    const int4 c = idx[i];
+    const int x = c.y >> 1, y = c.z >> 1, z = c.w >> 1;
+    if (x < out_sh.s[0] && y < out_sh.s[1] && z < out_sh.s[2]) {
+      const uint64_t key = lin_key(c.x, x, y, z, out_sh);
+      if (key < cells) {  // batch index or coordinate out of range: never touch memory past the bitmap
+        word = (long long)(key >> 6);
+        bits = 1ull << (key & 63);
+      }
+    }
+  }
+  const long long prev = __shfl_up(word, 1, 64);
+  const bool head = lane == 0 || prev != word;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const long long w = __shfl_down(word, d, 64);
+    const unsigned long long b = __shfl_down(bits, d, 64);
+    if (lane + d < 64 && w == word) bits |= b;
+  }
+  // up to 8 children share a cell and 64 cells a word: most runs find their bits already set and skip the atomic
+  if (head && word >= 0 && (__builtin_nontemporal_load(&bitmap[word]) & bits) != bits) atomicOr(&bitmap[word], bits);
 }
 
 // exclusive scan of one int per thread over a 256-thread block; returns the prefix, *total = block sum
