@@ -55,29 +55,32 @@ __global__ __launch_bounds__(kSortBlock) void radix_hist_kernel(
 // digit's total.  The 256 digit totals are turned into digit bases inside the scatter kernel.
 __global__ __launch_bounds__(256) void radix_scan_kernel(uint32_t* __restrict__ counts,
                                                          uint32_t* __restrict__ totals, int nchunks) {
-  __shared__ uint32_t part[256];
-  const int d = blockIdx.x, t = threadIdx.x;
+  __shared__ uint32_t wsum[4];
+  const int d = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
   uint32_t* row = counts + (int64_t)d * nchunks;
   const int per = (nchunks + 255) / 256;
   const int lo = t * per;
   const int hi = lo + per < nchunks ? lo + per : nchunks;
   uint32_t s = 0;
   for (int i = lo; i < hi; ++i) s += row[i];
-  part[t] = s;
-  __syncthreads();
-  for (int off = 1; off < 256; off <<= 1) {
-    const uint32_t v = t >= off ? part[t - off] : 0;
-    __syncthreads();
-    part[t] += v;
-    __syncthreads();
+  // block-wide inclusive scan of the 256 partial sums: shuffles inside a wave, one LDS round trip between waves
+  uint32_t inc = s;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t v = __shfl_up(inc, off, 64);
+    if (lane >= off) inc += v;
   }
-  uint32_t run = part[t] - s;
+  if (lane == 63) wsum[wave] = inc;
+  __syncthreads();
+  uint32_t before = 0;
+  for (int w = 0; w < wave; ++w) before += wsum[w];
+  uint32_t run = before + inc - s;
   for (int i = lo; i < hi; ++i) {
     const uint32_t v = row[i];
     row[i] = run;
     run += v;
   }
-  if (t == 255) totals[d] = part[255];
+  if (t == 255) totals[d] = before + inc;
 }
 
 __global__ __launch_bounds__(kSortBlock) void radix_scatter_kernel(
