@@ -139,6 +139,7 @@ int m3d_subm_rulebook(const int32_t* d_indices, int64_t n, const int64_t spatial
  *                             (batch, spatial_shape/2); first n_out rows valid
  *   d_pair_fwd    [8,n]  i32  pair_fwd[k][o] = i or -1 (column stride n)
  *   d_pair_bwd    [8,n]  i32  pair_bwd[k][i] = o or -1
+ *                 (columns at or beyond the row count - d_n_rows, else n - are left unwritten)
  *   d_n_out       [1]    i64
  *   batch_size: SparseConvTensor.batch_size (every batch index must be < batch_size)
  *   d_n_rows      [1]    i64  optional (NULL = all n rows): the number of valid rows of d_indices, read on

@@ -126,15 +126,25 @@ constexpr int kBitmapBlockWords = 1024;  // words per 256-thread block (4 per th
 // Below level 0 the voxels come in ascending linear order, so the lanes of a wave hit runs of the same bitmap word,
 // and atomics on one address are served one at a time: equal words in neighbouring lanes are OR-ed together by a
 // segmented shuffle reduction first and only the first lane of each run touches memory.
+// The same pass fills column i of both pair arrays with -1 (the pair kernel then writes the entries that exist):
+// there are at most as many output rows as input rows, so the live columns are covered without a memset of the
+// whole capacity.
 __global__ __launch_bounds__(256) void strided_mark_kernel(const int4* __restrict__ idx, int64_t n,
                                                            const int64_t* __restrict__ d_n, Shape3 out_sh,
-                                                           uint64_t cells, unsigned long long* __restrict__ bitmap) {
+                                                           uint64_t cells, unsigned long long* __restrict__ bitmap,
+                                                           int32_t* __restrict__ pair_fwd,
+                                                           int32_t* __restrict__ pair_bwd) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int lane = threadIdx.x & 63;
   // no early return: every lane takes part in the shuffles (an inactive lane carries word -1, bits 0)
   long long word = -1;
   unsigned long long bits = 0;
   if (i < n && !(d_n && i >= *d_n)) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      pair_fwd[(int64_t)k * n + i] = -1;
+      pair_bwd[(int64_t)k * n + i] = -1;
+    }
     const int4 c = idx[i];
     const int x = c.y >> 1, y = c.z >> 1, z = c.w >> 1;
     if (x < out_sh.s[0] && y < out_sh.s[1] && z < out_sh.s[2]) {
@@ -510,9 +520,8 @@ extern "C" int m3d_strided_rulebook(const int32_t* d_indices, int64_t n, const i
       return M3D_ENOSPC;
     }
     M3D_HIP(hipMemsetAsync(bitmap, 0, (size_t)nwords * sizeof(unsigned long long), stream));
-    M3D_HIP(hipMemsetAsync(d_pair_fwd, 0xFF, (size_t)8 * n * sizeof(int32_t), stream));
-    M3D_HIP(hipMemsetAsync(d_pair_bwd, 0xFF, (size_t)8 * n * sizeof(int32_t), stream));
-    hipLaunchKernelGGL(strided_mark_kernel, dim3(gb), dim3(bs), 0, stream, idx, n, d_n_rows, osh, drop_key, bitmap);
+    hipLaunchKernelGGL(strided_mark_kernel, dim3(gb), dim3(bs), 0, stream, idx, n, d_n_rows, osh, drop_key, bitmap,
+                       d_pair_fwd, d_pair_bwd);
     hipLaunchKernelGGL(bitmap_block_sum_kernel, dim3(nb), dim3(256), 0, stream, bitmap, nwords, bsum);
     hipLaunchKernelGGL(bitmap_scan_sums_kernel, dim3(1), dim3(256), 0, stream, bsum, nb, nout, d_n_out);
     hipLaunchKernelGGL(bitmap_prefix_kernel, dim3(nb), dim3(256), 0, stream, bitmap, nwords, bsum, prefix);
