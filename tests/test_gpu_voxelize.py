@@ -51,6 +51,18 @@ def test_scene_vs_oracle(device, seed, target):
     _check(out, oracle.sparsify(sc["coord"], sc["feat"], off, 0.02), "fnv")
 
 
+@pytest.mark.parametrize("n", [2, 63, 64, 65, 1023, 1024, 1025, 4095, 4096, 4097, 5000])
+def test_point_counts_around_the_one_workgroup_sort_limit(device, n):
+    """Up to 4096 keys the radix sort runs in one workgroup (sixteen waves, equal contiguous shares), above that in
+    three kernels per pass; the voxel order (ascending 64-bit FNV key, all eight passes) must not depend on it."""
+    rng = np.random.default_rng(n)
+    coord = (rng.random((n, 3)) * 40.0 - 20.0).astype(np.float32)  # nearly every point its own voxel
+    feat = rng.standard_normal((n, 3)).astype(np.float32)
+    off = np.array([0, n // 3, n], dtype=np.int64)
+    out = _run(coord, feat, off, 0.05, device)
+    _check(out, oracle.sparsify(coord, feat, off, 0.05), "fnv")
+
+
 def test_batch_with_empty_sample_and_offset_without_leading_zero(device):
     rng = np.random.default_rng(3)
     coord = (rng.random((900, 3)) * 1.5 - 0.7).astype(np.float32)
