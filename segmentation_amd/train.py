@@ -13,7 +13,6 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-from .sparse import segment_csr
 
 
 def unique_text_features(embeddings: Sequence[Sequence[torch.Tensor]]):
@@ -48,15 +47,28 @@ def caption_loss(point_features, text_features, labels_per_segment, point_indice
     if logit_scale is not None:
         logits = logit_scale.exp() * logits
     scores = F.log_softmax(logits, dim=-1)
-    rep = scores[point_indices if row_map is None else row_map[point_indices]]
-    reduced = segment_csr(rep, caption_offsets.to(device), reduce="mean")
-    loss = F.nll_loss(reduced, labels_per_segment.to(device), reduction="none")
+    # The reference gathers scores[point_indices] ([L, U]), averages it per caption and lets nll_loss pick the
+    # caption's own column.  Only that column is ever read, so the same number comes from one scalar per
+    # (point, caption) pair: loss_c = -mean_{p in c} scores[row(p), label_c].  The [L, U] tensor, its segment mean
+    # and their backward passes are never formed.
+    if reduction not in ("mean", "weighted_sum"):
+        raise ValueError(f"unknown reduction {reduction!r}")
+    rows = point_indices.to(device)
+    if row_map is not None:
+        rows = row_map[rows]
+    offsets = caption_offsets.to(device)
+    counts = offsets[1:] - offsets[:-1]
+    n_seg = counts.numel()
+    labels = labels_per_segment.to(device)
+    seg = torch.repeat_interleave(torch.arange(n_seg, device=device), counts, output_size=rows.numel())
+    picked = scores.reshape(-1).gather(0, rows * scores.shape[1] + labels[seg])
+    # F.nll_loss leaves out targets equal to its ignore_index (-100); a caption without points has mean 0
     if reduction == "mean":
-        return loss.mean()
-    if reduction == "weighted_sum":
-        w = num_points_per_caption.to(loss.device)
-        return (loss * w).sum() / w.sum()
-    raise ValueError(f"unknown reduction {reduction!r}")
+        coef = 1.0 / (counts.clamp(min=1).to(scores.dtype) * n_seg)
+    else:
+        w = num_points_per_caption.to(device)
+        coef = w.to(scores.dtype) / (counts.clamp(min=1).to(scores.dtype) * w.sum())
+    return -(picked * coef[seg]).sum()
 
 
 def flatten_caption_indices(batched_indices: Sequence[Sequence[torch.Tensor]], batch_offsets: torch.Tensor):
