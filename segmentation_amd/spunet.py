@@ -13,6 +13,7 @@ from typing import Dict, Sequence
 
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from . import ops, sparse
 
@@ -47,12 +48,32 @@ class PDBatchNorm(nn.Module):
         return self.bns[self.conditions.index(condition)]
 
     def forward(self, feat, condition=None, context=None):
-        feat = self.pick(condition)(feat)
-        if self.adaptive:
-            assert context is not None
-            shift, scale = self.modulation(context).chunk(2, dim=1)
-            feat = feat * (1.0 + scale) + shift
-        return feat
+        bn = self.pick(condition)
+        if not self.adaptive:
+            return bn(feat)
+        assert context is not None
+        shift, scale = self.modulation(context).chunk(2, dim=1)
+        if bn.affine and shift.shape[0] == 1 and feat.dim() == 2:
+            # One context row for the whole batch (ppt/model.py:15-22): bn(x)*(1+scale)+shift is the same batch
+            # norm with weight gamma*(1+scale) and bias beta*(1+scale)+shift, so the two [N, C] elementwise passes
+            # (and the three of their backward) become operations on [C] vectors.
+            gain = 1.0 + scale[0]
+            return _batch_norm_with(bn, feat, bn.weight * gain, bn.bias * gain + shift[0])
+        return bn(feat) * (1.0 + scale) + shift
+
+
+def _batch_norm_with(bn, x, weight, bias):
+    """nn.BatchNorm1d.forward of `bn` with another affine pair: same statistics, running-average update and
+    batch counter."""
+    factor = 0.0 if bn.momentum is None else bn.momentum
+    if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+        if bn.momentum is None:
+            factor = 1.0 / float(bn.num_batches_tracked)
+    use_batch_stats = bn.training or (bn.running_mean is None and bn.running_var is None)
+    keep_running = not bn.training or bn.track_running_stats
+    return F.batch_norm(x, bn.running_mean if keep_running else None, bn.running_var if keep_running else None,
+                        weight, bias, use_batch_stats, factor, bn.eps)
 
 
 class ConvNormAct(nn.Module):
