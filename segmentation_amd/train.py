@@ -15,15 +15,54 @@ import torch.nn.functional as F
 
 
 
+_ROW_HASH_WEIGHTS = {}
+
+
+def _unique_rows_on_device(text: torch.Tensor):
+    """np.unique(text, axis=0, return_index=True, return_inverse=True) for a [S, D] float32 tensor on the GPU.
+
+    torch.unique(dim=0) sorts whole rows in one workgroup (8.5 ms for 1200 x 768).  Here equal rows are grouped by a
+    64-bit hash of their bit patterns, the group representatives (first occurrences) are put into lexicographic
+    order by stable sorts on their four leading columns, and the result is verified: every row must equal its
+    representative and no two neighbouring representatives may tie on those columns.  A failed check (a hash
+    collision, or rows that agree on four columns) falls back to torch.unique(dim=0)."""
+    s, d = text.shape
+    lead = min(4, d)
+    key = (d, text.device)
+    weights = _ROW_HASH_WEIGHTS.get(key)
+    if weights is None:
+        g = torch.Generator().manual_seed(0x5EED)
+        weights = (torch.randint(-(1 << 62), 1 << 62, (d,), generator=g, dtype=torch.int64) | 1).to(text.device)
+        _ROW_HASH_WEIGHTS[key] = weights
+    bits = (text.detach().float() + 0.0).contiguous().view(torch.int32).to(torch.int64)  # -0.0 -> +0.0
+    _, inv = torch.unique((bits * weights).sum(1), return_inverse=True)
+    u = int(inv.max()) + 1
+    first = torch.full((u,), s, dtype=torch.int64, device=text.device)
+    first.scatter_reduce_(0, inv, torch.arange(s, device=text.device), reduce="amin")
+    reps = text[first]
+    order = torch.arange(u, device=text.device)
+    for c in range(lead - 1, -1, -1):
+        order = order[torch.sort(reps[order, c], stable=True).indices]
+    reps, first = reps[order], first[order]
+    rank = torch.empty_like(order)
+    rank[order] = torch.arange(u, device=text.device)
+    inverse = rank[inv]
+    ok = (reps[inverse] == text).all()
+    if u > 1:
+        ok = ok & (reps[1:, :lead] != reps[:-1, :lead]).any(1).all()
+    if not bool(ok):
+        uniq, inverse = torch.unique(text.detach(), dim=0, return_inverse=True)
+        first = torch.full((uniq.shape[0],), s, dtype=torch.int64, device=text.device)
+        first.scatter_reduce_(0, inverse, torch.arange(s, device=text.device), reduce="amin")
+    return first, inverse
+
+
 def unique_text_features(embeddings: Sequence[Sequence[torch.Tensor]]):
     """extract_text_features with precomputed embeddings (caption_loss.py:30-39): unique rows of the stacked
     caption embeddings (np.unique along axis 0) -> (text_features [U,D], labels_per_segment [S], labels_per_caption [U])."""
     text = torch.stack([item for sub in embeddings for item in sub], 0)
     if text.is_cuda:  # same result (rows in lexicographic order, first occurrences) without leaving the device
-        uniq, inverse = torch.unique(text.detach(), dim=0, return_inverse=True)
-        s = text.shape[0]
-        first = torch.full((uniq.shape[0],), s, dtype=torch.int64, device=text.device)
-        first.scatter_reduce_(0, inverse, torch.arange(s, device=text.device), reduce="amin")
+        first, inverse = _unique_rows_on_device(text)
         return text[first], inverse, first
     device = text.device
     _, first, inverse = np.unique(text.detach().cpu().numpy(), return_index=True, return_inverse=True, axis=0)

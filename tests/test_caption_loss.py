@@ -65,3 +65,22 @@ def test_row_map_and_unknown_reduction():
     assert abs(a.item() - b.item()) < 1e-13
     with pytest.raises(ValueError):
         train.caption_loss(vox, text, labels, pi, offsets, w, row_map=v2p, reduction="sum")
+
+
+@pytest.mark.parametrize("tie_on_leading_columns", [False, True])
+def test_unique_rows_equals_numpy_unique_axis0(tie_on_leading_columns):
+    """The device routine of unique_text_features (hash grouping + leading-column order, verified, with a
+    torch.unique(dim=0) fallback) is plain torch code: run it on the CPU against np.unique(axis=0)."""
+    rng = np.random.default_rng(9)
+    pool = torch.from_numpy(rng.normal(size=(40, 12)).astype(np.float32))
+    pool[3, 0] = -0.0
+    pool[4] = pool[3]
+    pool[4, 0] = 0.0  # equal to row 3 for np.unique, different bits
+    if tie_on_leading_columns:
+        pool[6, :4] = pool[5, :4]
+    text = pool[torch.from_numpy(rng.integers(0, 40, size=300))]
+    first, inverse = train._unique_rows_on_device(text)
+    uniq, f_ref, i_ref = np.unique(text.numpy(), return_index=True, return_inverse=True, axis=0)
+    assert np.array_equal(text[first].numpy(), uniq)
+    assert np.array_equal(inverse.numpy(), np.asarray(i_ref).reshape(-1))
+    assert np.array_equal(first.numpy(), f_ref)
