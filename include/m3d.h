@@ -245,15 +245,23 @@ int m3d_conv_fwd_sf32(const void* d_in0, int c0, int64_t rows0, const void* d_in
  *   - strided k2 s2: over the schedule of pair_bwd, weights W[k]^T;  its inverse: over the schedule of pair_fwd;
  *   - 1x1: dense, weights W^T.
  *
- * Weight gradient:  dW[co][k][ci] = sum_t dout[out_row[t]][co] * in[nbr[k][t]][ci], exact f32
- * (v_mfma_f32_32x32x2_f32), deterministic.  cin and cout must be multiples of 32 (pad the 3-channel stem input
+ * Weight gradient:  dW[co][k][ci] = sum_t dout[out_row[t]][co] * in[nbr[k][t]][ci], deterministic (partial sums
+ * are combined in a fixed order, no atomics).  cin and cout must be multiples of 32 (pad the 3-channel stem input
  * with zero channels).  d_dweight has the reference layout [cout, k, cin].
+ *   m3d_conv_bwd_weight_f32     exact f32 products (v_mfma_f32_32x32x2_f32)
+ *   m3d_conv_bwd_weight_bf16x3  every f32 operand split into two bf16 terms in registers, products
+ *                               hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16, f32 accumulation (relative error
+ *                               of a gradient ~1e-5); same arguments and workspace
  */
 size_t m3d_conv_bwd_weight_workspace_bytes(int64_t n, int cin, int cout, int k);
 int m3d_conv_bwd_weight_f32(const float* d_in, int cin, const float* d_dout, int cout, int k,
                             const int32_t* d_nbr, const int32_t* d_out_row, const uint32_t* d_tile_mask,
                             int64_t n, int64_t npad, float* d_dweight, void* d_ws, size_t ws_bytes,
                             void* stream);
+int m3d_conv_bwd_weight_bf16x3(const float* d_in, int cin, const float* d_dout, int cout, int k,
+                               const int32_t* d_nbr, const int32_t* d_out_row, const uint32_t* d_tile_mask,
+                               int64_t n, int64_t npad, float* d_dweight, void* d_ws, size_t ws_bytes,
+                               void* stream);
 
 /* Halo of a tile schedule (optional accelerator of m3d_conv_fwd_sf32 with terms = 2, meant for 3x3x3
  * submanifold maps of large levels).  For every tile of m3d_halo_tile_rows() = 256 schedule rows: the

@@ -28,6 +28,37 @@ struct BwdWArgs {
   int cin, cout, kvol, nsplit;
 };
 
+// Combine the four waves' partial sums through LDS (fixed order), then one store per element of the
+// (split, offset) slab.
+template <int TA, int TB>
+__device__ __forceinline__ void bwd_weight_store(const BwdWArgs& a, floatx16 (&acc)[TA][TB], int k, int split, int co0,
+                                                 int ci0, int lane, int wave, int c, int h) {
+  __shared__ float red[3][TA * TB * 1024];  // waves 1..3
+  if (wave > 0) {
+#pragma unroll
+    for (int x = 0; x < TA; ++x)
+#pragma unroll
+      for (int y = 0; y < TB; ++y)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[wave - 1][((x * TB + y) * 16 + r) * 64 + lane] = acc[x][y][r];
+  }
+  __syncthreads();
+  if (wave == 0) {
+    float* dst = a.slab + (((int64_t)split * a.kvol + k) * a.cout) * a.cin;
+#pragma unroll
+    for (int x = 0; x < TA; ++x)
+#pragma unroll
+      for (int y = 0; y < TB; ++y)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int e = ((x * TB + y) * 16 + r) * 64 + lane;
+          const float v = ((acc[x][y][r] + red[0][e]) + red[1][e]) + red[2][e];
+          const int m = (r & 3) + 8 * (r >> 2) + 4 * h;  // accumulator register r of lane (c, h) is row m, column c
+          dst[(int64_t)(co0 + x * 32 + m) * a.cin + ci0 + y * 32 + c] = v;
+        }
+  }
+}
+
 template <int TA, int TB>
 __global__ __launch_bounds__(256) void conv_bwd_weight_kernel(BwdWArgs a) {
   const int k = blockIdx.x, split = blockIdx.z;
@@ -71,31 +102,85 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_kernel(BwdWArgs a) {
         for (int y = 0; y < TB; ++y) acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[x], bv[y], acc[x][y], 0, 0, 0);
     }
   }
-  // combine the four waves through LDS (fixed order), then one store per element
-  __shared__ float red[3][TA * TB * 1024];  // waves 1..3
-  if (wave > 0) {
+  bwd_weight_store<TA, TB>(a, acc, k, split, co0, ci0, lane, wave, c, h);
+}
+
+// The same reduction with split-bf16 products on v_mfma_f32_32x32x16_bf16: sixteen schedule rows per issue, lane
+// (c, h) holds channel c of rows t + 8h .. t + 8h + 7 for both operands (eight 128-byte row segments each, straight
+// from global memory), splits every value into hi = bf16(v) and lo = bf16(v - hi) in registers and forms
+// hi*hi + hi*lo + lo*hi in the f32 accumulator.  One sixteenth of the matrix-pipe time of the f32 instruction per
+// product; what remains is the gather.
+template <int TA, int TB>
+__global__ __launch_bounds__(256) void conv_bwd_weight_split_kernel(BwdWArgs a) {
+  const int k = blockIdx.x, split = blockIdx.z;
+  const int tiles_ci = a.cin / (32 * TB);
+  const int co0 = (blockIdx.y / tiles_ci) * 32 * TA, ci0 = (blockIdx.y % tiles_ci) * 32 * TB;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = lane & 31, h = lane >> 5;
+  const int64_t ntile = a.npad / 32;
+  const int64_t per = (ntile + a.nsplit - 1) / a.nsplit;
+  const int64_t tile0 = (int64_t)split * per, tile1 = tile0 + per < ntile ? tile0 + per : ntile;
+  floatx16 acc[TA][TB];
 #pragma unroll
-    for (int x = 0; x < TA; ++x)
+  for (int i = 0; i < TA; ++i)
 #pragma unroll
-      for (int y = 0; y < TB; ++y)
+    for (int j = 0; j < TB; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) red[wave - 1][((x * TB + y) * 16 + r) * 64 + lane] = acc[x][y][r];
-  }
-  __syncthreads();
-  if (wave == 0) {
-    float* dst = a.slab + (((int64_t)split * a.kvol + k) * a.cout) * a.cin;
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const float* dout_c = a.dout + co0 + c;
+  const float* in_c = a.in + ci0 + c;
+  for (int64_t tile = tile0 + wave; tile < tile1; tile += 4) {
+    if (a.tile_mask && !((a.tile_mask[tile] >> k) & 1u)) continue;
 #pragma unroll
-    for (int x = 0; x < TA; ++x)
+    for (int s = 0; s < 32; s += 16) {
+      const int64_t t0 = tile * 32 + s + 8 * h;
+      int jj[8], ii[8];
+      if (a.nbr) {
+        const int4 j0 = *reinterpret_cast<const int4*>(a.out_row + t0);
+        const int4 j1 = *reinterpret_cast<const int4*>(a.out_row + t0 + 4);
+        const int4 i0 = *reinterpret_cast<const int4*>(a.nbr + (int64_t)k * a.npad + t0);
+        const int4 i1 = *reinterpret_cast<const int4*>(a.nbr + (int64_t)k * a.npad + t0 + 4);
+        jj[0] = j0.x; jj[1] = j0.y; jj[2] = j0.z; jj[3] = j0.w; jj[4] = j1.x; jj[5] = j1.y; jj[6] = j1.z; jj[7] = j1.w;
+        ii[0] = i0.x; ii[1] = i0.y; ii[2] = i0.z; ii[3] = i0.w; ii[4] = i1.x; ii[5] = i1.y; ii[6] = i1.z; ii[7] = i1.w;
+      } else {
 #pragma unroll
-      for (int y = 0; y < TB; ++y)
+        for (int i = 0; i < 8; ++i) jj[i] = ii[i] = t0 + i < a.n ? (int)(t0 + i) : -1;
+      }
+      float av[TA][8], bv[TB][8];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int e = ((x * TB + y) * 16 + r) * 64 + lane;
-          const float v = ((acc[x][y][r] + red[0][e]) + red[1][e]) + red[2][e];
-          const int m = (r & 3) + 8 * (r >> 2) + 4 * h;  // accumulator register r of lane (c, h) is row m, column c
-          dst[(int64_t)(co0 + x * 32 + m) * a.cin + ci0 + y * 32 + c] = v;
+      for (int i = 0; i < 8; ++i) {
+        const bool ok = jj[i] >= 0 && ii[i] >= 0;
+#pragma unroll
+        for (int x = 0; x < TA; ++x) av[x][i] = ok ? dout_c[(int64_t)jj[i] * a.cout + x * 32] : 0.f;
+#pragma unroll
+        for (int x = 0; x < TB; ++x) bv[x][i] = ok ? in_c[(int64_t)ii[i] * a.cin + x * 32] : 0.f;
+      }
+      bf16x8 ahi[TA], alo[TA], bhi[TB], blo[TB];
+#pragma unroll
+      for (int x = 0; x < TA; ++x)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          ahi[x][i] = (__bf16)av[x][i];
+          alo[x][i] = (__bf16)(av[x][i] - (float)ahi[x][i]);
         }
+#pragma unroll
+      for (int x = 0; x < TB; ++x)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          bhi[x][i] = (__bf16)bv[x][i];
+          blo[x][i] = (__bf16)(bv[x][i] - (float)bhi[x][i]);
+        }
+#pragma unroll
+      for (int x = 0; x < TA; ++x)
+#pragma unroll
+        for (int y = 0; y < TB; ++y) {
+          acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo[x], bhi[y], acc[x][y], 0, 0, 0);
+          acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[x], blo[y], acc[x][y], 0, 0, 0);
+          acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[x], bhi[y], acc[x][y], 0, 0, 0);
+        }
+    }
   }
+  bwd_weight_store<TA, TB>(a, acc, k, split, co0, ci0, lane, wave, c, h);
 }
 
 // dW[co][k][ci] (reference layout) = sum over splits of slab[s][k][co][ci], in split order
@@ -134,12 +219,11 @@ extern "C" size_t m3d_conv_bwd_weight_workspace_bytes(int64_t n, int cin, int co
   return align_up((size_t)nsplit * k * cout * cin * sizeof(float));
 }
 
-extern "C" int m3d_conv_bwd_weight_f32(const float* d_in, int cin, const float* d_dout, int cout, int k,
-                                       const int32_t* d_nbr, const int32_t* d_out_row, const uint32_t* d_tile_mask,
-                                       int64_t n, int64_t npad, float* d_dweight, void* d_ws, size_t ws_bytes,
-                                       void* stream_) {
+static int conv_bwd_weight_launch(const char* who, bool split_products, const float* d_in, int cin, const float* d_dout,
+                                  int cout, int k, const int32_t* d_nbr, const int32_t* d_out_row,
+                                  const uint32_t* d_tile_mask, int64_t n, int64_t npad, float* d_dweight, void* d_ws,
+                                  size_t ws_bytes, void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
-  const char* who = "m3d_conv_bwd_weight_f32";
   M3D_CHECK_ARG(n > 0 && d_in && d_dout && d_dweight, "%s: null pointer or empty input", who);
   M3D_CHECK_ARG(cin > 0 && cout > 0 && cin % 32 == 0 && cout % 32 == 0 && k >= 1 && k <= 27,
                 "%s: channel counts must be multiples of 32 (pad the input), 1 <= k <= 27", who);
@@ -159,12 +243,33 @@ extern "C" int m3d_conv_bwd_weight_f32(const float* d_in, int cin, const float* 
   }
   BwdWArgs a{d_in, d_dout, d_nbr, d_out_row, d_tile_mask, static_cast<float*>(d_ws), n, npad, cin, cout, k, nsplit};
   dim3 grid((unsigned)k, (unsigned)tiles, (unsigned)nsplit);
-#define M3D_BW(TA_, TB_) \
-  if (ta == TA_ && tb == TB_) hipLaunchKernelGGL((conv_bwd_weight_kernel<TA_, TB_>), grid, dim3(256), 0, stream, a);
+#define M3D_BW(TA_, TB_)                                                                                      \
+  if (ta == TA_ && tb == TB_) {                                                                                \
+    if (split_products)                                                                                        \
+      hipLaunchKernelGGL((conv_bwd_weight_split_kernel<TA_, TB_>), grid, dim3(256), 0, stream, a);             \
+    else                                                                                                       \
+      hipLaunchKernelGGL((conv_bwd_weight_kernel<TA_, TB_>), grid, dim3(256), 0, stream, a);                   \
+  }
   M3D_BW(1, 1) M3D_BW(1, 2) M3D_BW(1, 3) M3D_BW(2, 1) M3D_BW(2, 2) M3D_BW(2, 3) M3D_BW(3, 1) M3D_BW(3, 2) M3D_BW(3, 3)
 #undef M3D_BW
   hipLaunchKernelGGL(conv_bwd_weight_reduce_kernel, dim3((unsigned)cdiv((int64_t)k * cout * cin, 256)), dim3(256), 0, stream,
                      a.slab, nsplit, k, cout, cin, d_dweight);
   M3D_LAUNCH_CHECK();
   return M3D_OK;
+}
+
+extern "C" int m3d_conv_bwd_weight_f32(const float* d_in, int cin, const float* d_dout, int cout, int k,
+                                       const int32_t* d_nbr, const int32_t* d_out_row, const uint32_t* d_tile_mask,
+                                       int64_t n, int64_t npad, float* d_dweight, void* d_ws, size_t ws_bytes,
+                                       void* stream) {
+  return conv_bwd_weight_launch("m3d_conv_bwd_weight_f32", false, d_in, cin, d_dout, cout, k, d_nbr, d_out_row,
+                                d_tile_mask, n, npad, d_dweight, d_ws, ws_bytes, stream);
+}
+
+extern "C" int m3d_conv_bwd_weight_bf16x3(const float* d_in, int cin, const float* d_dout, int cout, int k,
+                                          const int32_t* d_nbr, const int32_t* d_out_row, const uint32_t* d_tile_mask,
+                                          int64_t n, int64_t npad, float* d_dweight, void* d_ws, size_t ws_bytes,
+                                          void* stream) {
+  return conv_bwd_weight_launch("m3d_conv_bwd_weight_bf16x3", true, d_in, cin, d_dout, cout, k, d_nbr, d_out_row,
+                                d_tile_mask, n, npad, d_dweight, d_ws, ws_bytes, stream);
 }

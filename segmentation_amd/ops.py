@@ -417,9 +417,10 @@ def conv_fwd(in0, weight_packed: PackedWeight, sched: Optional[Schedule], n_out,
 
 
 # ----------------------------------------------------------------------------- head
-def conv_bwd_weight(x, dout, sched, k):
-    """Weight gradient of a sparse convolution (m3d_conv_bwd_weight_f32): x [n_in, Cin] f32 the layer's input,
-    dout [n_out, Cout] f32 the gradient of its output, sched the schedule the forward ran on (None = dense 1x1).
+def conv_bwd_weight(x, dout, sched, k, precision="f32"):
+    """Weight gradient of a sparse convolution (m3d_conv_bwd_weight_f32 / _bf16x3): x [n_in, Cin] f32 the layer's
+    input, dout [n_out, Cout] f32 the gradient of its output, sched the schedule the forward ran on (None = dense
+    1x1), precision "f32" (exact products) or "bf16x3" (two-term bf16 splits, three products).
     Returns dW [Cout, k, Cin] f32.  Channel counts that are not multiples of 32 (the 3-channel stem) are
     zero-padded for the kernel and the padding is dropped from the result."""
     lib = _lib.load()
@@ -444,9 +445,12 @@ def conv_bwd_weight(x, dout, sched, k):
             raise ValueError("schedule does not match the output gradient")
         nbr, orow, mask, npad = sched.nbr, sched.out_row, sched.tile_mask, sched.npad
     ws = _workspace(lib.m3d_conv_bwd_weight_workspace_bytes(n, ci, co, k), dev)
-    rc = lib.m3d_conv_bwd_weight_f32(_ptr(xk), ci, _ptr(dk), co, k, _ptr(nbr), _ptr(orow), _ptr(mask), n, npad,
-                                     _ptr(dw), _ptr(ws), ws.numel(), _stream())
-    _lib.check(rc, "m3d_conv_bwd_weight_f32")
+    if precision not in ("f32", "bf16x3"):
+        raise ValueError(f"conv_bwd_weight: precision {precision!r} (f32 or bf16x3)")
+    name = "m3d_conv_bwd_weight_" + precision
+    rc = getattr(lib, name)(_ptr(xk), ci, _ptr(dk), co, k, _ptr(nbr), _ptr(orow), _ptr(mask), n, npad,
+                            _ptr(dw), _ptr(ws), ws.numel(), _stream())
+    _lib.check(rc, name)
     return dw[:cout, :, :cin] if (pin or pout) else dw
 
 

@@ -292,8 +292,9 @@ class SparseConvolution(SparseModule):
 class _SparseConvFn(torch.autograd.Function):
     """out = conv(feats, weight) + bias through m3d_conv_fwd_f32; the input gradient is the forward kernel on the
     transposed weights over the transposed kernel map (for a submanifold map: the same schedule with the kernel
-    offsets reversed), the weight gradient is m3d_conv_bwd_weight_f32 (always exact f32 products).  Forward and
-    input gradient form their products as set_precision() says (f32 activations are split inside the kernel)."""
+    offsets reversed), the weight gradient is m3d_conv_bwd_weight_f32 / _bf16x3.  All three form their products as
+    set_precision() says (f32 activations are split inside the kernels; "bf16x6" keeps the exact f32 weight
+    gradient)."""
 
     @staticmethod
     def forward(ctx, feats, weight, bias, sched_fwd, sched_back, n_out, n_in, flip):
@@ -318,7 +319,8 @@ class _SparseConvFn(torch.autograd.Function):
                 wt = wt.flip(1)
             dx = ops.conv_fwd(dout, ops.pack_weight(wt.contiguous(), precision), sched_back, n_in)
         if ctx.needs_input_grad[1]:
-            dw = ops.conv_bwd_weight(feats, dout, sched_fwd, k).reshape(weight.shape)
+            dw = ops.conv_bwd_weight(feats, dout, sched_fwd, k,
+                                     precision="bf16x3" if precision == "bf16x3" else "f32").reshape(weight.shape)
         if has_bias and ctx.needs_input_grad[2]:
             db = dout.sum(0)
         return dx, dw, db, None, None, None, None, None
