@@ -141,22 +141,34 @@ __global__ void vox_coords_kernel(const int32_t* __restrict__ rep, const int4* _
   if (r < *d_count) voxel_coords[r] = bc[rep[r]];
 }
 
-__global__ void vox_accum_kernel(const float* __restrict__ feat, const int32_t* __restrict__ inverse,
-                                 int64_t n, int c, double* __restrict__ sums, int32_t* __restrict__ cnt,
-                                 int64_t* __restrict__ v2p) {
+// Mean pooling without an atomic per feature: every point pushes itself onto its voxel's list (one exchange per
+// point; scattered device-scope atomics are what bounds this stage), then one thread per (voxel, channel) walks the
+// list.  The walk adds in float64, so the float32 mean does not depend on the order the points arrived in.
+__global__ void vox_link_kernel(const int32_t* __restrict__ inverse, int64_t n, int32_t* __restrict__ head,
+                                int32_t* __restrict__ next, int64_t* __restrict__ v2p) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const int r = inverse[i];
   v2p[i] = r;
-  atomicAdd(&cnt[r], 1);
-  for (int j = 0; j < c; ++j) atomicAdd(&sums[(int64_t)r * c + j], (double)feat[i * c + j]);
+  next[i] = atomicExch(&head[r], (int32_t)i);
 }
 
-__global__ void vox_mean_kernel(const double* __restrict__ sums, const int32_t* __restrict__ cnt,
-                                const int* __restrict__ d_count, int c, float* __restrict__ voxel_feats) {
+__global__ void vox_mean_kernel(const float* __restrict__ feat, const int32_t* __restrict__ head,
+                                const int32_t* __restrict__ next, const int* __restrict__ d_count, int c,
+                                float* __restrict__ voxel_feats, int32_t* __restrict__ cnt) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t total = (int64_t)(*d_count) * c;
-  if (t < total) voxel_feats[t] = (float)(sums[t] / (double)cnt[t / c]);
+  const int cc = c > 0 ? c : 1;  // c == 0: counts only
+  if (t >= (int64_t)(*d_count) * cc) return;
+  const int64_t r = t / cc;
+  const int j = (int)(t % cc);
+  double sum = 0.0;
+  int m = 0;
+  for (int32_t p = head[r]; p >= 0; p = next[p]) {
+    if (c > 0) sum += (double)feat[(int64_t)p * c + j];
+    ++m;
+  }
+  if (c > 0) voxel_feats[t] = (float)(sum / (double)m);
+  if (j == 0) cnt[r] = m;
 }
 
 __global__ void vox_meta_kernel(const int* __restrict__ mm, const int* __restrict__ d_count, int pad,
@@ -243,15 +255,15 @@ static int voxelize_impl(const char* who, const float* d_coord, const float* d_f
   M3D_LAUNCH_CHECK();
   int rc = unique_sorted(w.keys, n, 64, ukeys, w.rep, w.inverse, w.count, w.uniq, w.uniq_bytes, stream);
   if (rc != M3D_OK) return rc;
-  if (c > 0) M3D_HIP(hipMemsetAsync(w.sums, 0, (size_t)n * c * sizeof(double), stream));
-  M3D_HIP(hipMemsetAsync(w.cnt, 0, (size_t)n * sizeof(int32_t), stream));
+  // list heads and links live where the per-voxel sums used to: 2 * n int32 <= n * max(c, 1) doubles
+  int32_t* head = reinterpret_cast<int32_t*>(w.sums);
+  int32_t* next = head + n;
+  M3D_HIP(hipMemsetAsync(head, 0xFF, (size_t)n * sizeof(int32_t), stream));
   hipLaunchKernelGGL(vox_coords_kernel, dim3(gb), dim3(bs), 0, stream, w.rep, w.bc, w.count,
                      reinterpret_cast<int4*>(d_voxel_coords));
-  hipLaunchKernelGGL(vox_accum_kernel, dim3(gb), dim3(bs), 0, stream, d_feat, w.inverse, n, c, w.sums,
-                     w.cnt, d_v2p_map);
-  if (c > 0)
-    hipLaunchKernelGGL(vox_mean_kernel, dim3((unsigned)cdiv(n * c, bs)), dim3(bs), 0, stream, w.sums,
-                       w.cnt, w.count, c, d_voxel_feats);
+  hipLaunchKernelGGL(vox_link_kernel, dim3(gb), dim3(bs), 0, stream, w.inverse, n, head, next, d_v2p_map);
+  hipLaunchKernelGGL(vox_mean_kernel, dim3((unsigned)cdiv(n * (c > 0 ? c : 1), bs)), dim3(bs), 0, stream, d_feat, head,
+                     next, w.count, c, d_voxel_feats, w.cnt);
   if (d_count_out) hipLaunchKernelGGL(copy_counts_kernel, dim3(gb), dim3(bs), 0, stream, w.cnt, w.count, d_count_out);
   hipLaunchKernelGGL(vox_meta_kernel, dim3(1), dim3(64), 0, stream, w.mm, w.count, pad, d_meta);
   M3D_LAUNCH_CHECK();
