@@ -11,6 +11,7 @@ Conventions kept from spconv 2.x so that existing checkpoints load: conv weights
 [Cout, k0, k1, k2, Cin]; SubMConv3d / SparseConv3d / SparseInverseConv3d are siblings (the
 reference's _init_weights uses isinstance(m, SubMConv3d), v1m3:362-378)."""
 import enum
+import os
 import math
 from collections import OrderedDict
 from typing import List, Optional, Sequence, Union
@@ -289,6 +290,17 @@ class SparseConvolution(SparseModule):
                                 x.indice_dict, x.benchmark)
 
 
+_SPLIT_FIRST_ROWS = int(os.environ.get("M3D_SPLIT_FIRST_ROWS", "5000"))
+
+
+def _maybe_split(x, w):
+    """Large f32 activations of a bf16x3 convolution are split into the two-term format once, so that the
+    convolution runs on the LDS-DMA kernel; small ones are split inside the register-staged kernel."""
+    if w.precision == "bf16x3" and x.shape[1] % 32 == 0 and _SPLIT_FIRST_ROWS and x.shape[0] >= _SPLIT_FIRST_ROWS:
+        return ops.split_f32(x, 2)
+    return x
+
+
 class _SparseConvFn(torch.autograd.Function):
     """out = conv(feats, weight) + bias through m3d_conv_fwd_f32; the input gradient is the forward kernel on the
     transposed weights over the transposed kernel map (for a submanifold map: the same schedule with the kernel
@@ -300,7 +312,8 @@ class _SparseConvFn(torch.autograd.Function):
     def forward(ctx, feats, weight, bias, sched_fwd, sched_back, n_out, n_in, flip):
         feats = feats.contiguous()
         w = ops.pack_weight(weight.detach(), _PRECISION)
-        out = ops.conv_fwd(feats, w, sched_fwd, n_out, shift=None if bias is None else bias.detach().float().contiguous())
+        out = ops.conv_fwd(_maybe_split(feats, w), w, sched_fwd, n_out,
+                           shift=None if bias is None else bias.detach().float().contiguous())
         ctx.save_for_backward(feats, weight)
         ctx.meta = (sched_fwd, sched_back, n_out, n_in, flip, bias is not None, _PRECISION)
         return out
@@ -317,7 +330,8 @@ class _SparseConvFn(torch.autograd.Function):
             wt = weight.detach().reshape(cout, k, cin).permute(2, 1, 0)  # [Cin, k, Cout]
             if flip:
                 wt = wt.flip(1)
-            dx = ops.conv_fwd(dout, ops.pack_weight(wt.contiguous(), precision), sched_back, n_in)
+            wt = ops.pack_weight(wt.contiguous(), precision)
+            dx = ops.conv_fwd(_maybe_split(dout, wt), wt, sched_back, n_in)
         if ctx.needs_input_grad[1]:
             dw = ops.conv_bwd_weight(feats, dout, sched_fwd, k,
                                      precision="bf16x3" if precision == "bf16x3" else "f32").reshape(weight.shape)
