@@ -8,6 +8,7 @@ mosaic3d/src/models/networks/ppt/model.py:7-22; voxelisation follows Point.spars
 
 This module is the layer-by-layer (unfused) path; segmentation_amd.engine runs the same network
 with folded norms and fused epilogues."""
+import os
 from collections import OrderedDict
 from typing import Dict, Sequence
 
@@ -51,6 +52,9 @@ class PDBatchNorm(nn.Module):
         bn = self.pick(condition)
         if not self.adaptive:
             return bn(feat)
+        pre = self.__dict__.pop("_affine", None)  # set for one call by SpUNet.forward (all norms in one product)
+        if pre is not None and feat.dim() == 2:
+            return _batch_norm_with(bn, feat, pre[0], pre[1])
         assert context is not None
         shift, scale = self.modulation(context).chunk(2, dim=1)
         if bn.affine and shift.shape[0] == 1 and feat.dim() == 2:
@@ -184,12 +188,38 @@ class SpUNet(nn.Module):
                                     vox["batch_size"])
         return x, vox
 
+    def _fold_modulations(self, condition, context, dtype):
+        """With one context row per batch every PDBatchNorm of the network reduces to a batch norm with weight
+        gamma*(1+scale) and bias beta*(1+scale)+shift (see PDBatchNorm.forward).  All of them are formed here from
+        two matrix-vector products over the concatenated modulation weights, instead of 59 products and five
+        [C]-vector kernels per norm; each norm picks its slice up on its next call."""
+        norms = self.__dict__.get("_pd_norms")
+        if norms is None:
+            norms = [m for m in self.modules() if isinstance(m, PDBatchNorm) and m.adaptive and m.affine]
+            self.__dict__["_pd_norms"] = norms
+        if context is None or context.shape[0] != 1 or not norms or os.environ.get("M3D_FOLD_MODULATIONS", "1") == "0":
+            return
+        sizes = [m.modulation[1].out_features // 2 for m in norms]
+        lin = [m.modulation[1] for m in norms]
+        act = F.silu(context.to(dtype))
+        shift = F.linear(act, torch.cat([l.weight[:c] for l, c in zip(lin, sizes)]),
+                         torch.cat([l.bias[:c] for l, c in zip(lin, sizes)]))[0]
+        scale = F.linear(act, torch.cat([l.weight[c:] for l, c in zip(lin, sizes)]),
+                         torch.cat([l.bias[c:] for l, c in zip(lin, sizes)]))[0]
+        bns = [m.pick(condition) for m in norms]
+        gain = 1.0 + scale
+        weight = torch.cat([b.weight for b in bns]) * gain
+        bias = torch.cat([b.bias for b in bns]) * gain + shift
+        for m, w, b in zip(norms, weight.split(sizes), bias.split(sizes)):
+            m.__dict__["_affine"] = (w, b)
+
     def forward(self, input_dict):
         """Returns dict(sparse_conv_feat, feat [N0, out], v2p_map [N_pts]) -- the fields of the
         reference's Point that the head reads (language_module.py:202-207)."""
         x, vox = self.sparsify(input_dict)
         condition = input_dict["condition"][0]
         context = input_dict.get("context")
+        self._fold_modulations(condition, context, x.features.dtype)
         x = self.conv_input([x, condition, context])
         if context is not None:
             context = context.to(x.features.dtype)

@@ -216,7 +216,7 @@ class _CpuConvs:
         sparse.SparseConvolution.forward, spunet.SpUNet.sparsify = self._fwd, self._sparsify
 
 
-def test_whole_training_step_matches_cpu_oracle(device):
+def test_whole_training_step_matches_cpu_oracle(device, monkeypatch):
     torch.manual_seed(0)
     cfg = dict(spunet.SPUNET18A, out_channels=64, channels=(32, 64, 64, 96, 96, 64, 32, 32), layers=(1, 1, 1, 1, 1, 1, 1, 1))
     net = spunet.PPT(spunet.SpUNet(in_channels=cfg["in_channels"], out_channels=cfg["out_channels"],
@@ -240,6 +240,8 @@ def test_whole_training_step_matches_cpu_oracle(device):
     bc = dict(coord=torch.from_numpy(sc["coord"]), feat=torch.from_numpy(sc["feat"]), offset=torch.tensor([0, n]),
               grid_size=0.02, condition=["ScanNet"], caption_data=cdc)
     ref.train()
+    # the CPU copy forms every norm's modulation on its own; the GPU model above folds all of them in one product
+    monkeypatch.setenv("M3D_FOLD_MODULATIONS", "0")
     with _CpuConvs():
         out = ref(bc)
         text, seg, _ = train.unique_text_features(cdc["embedding"])
@@ -257,6 +259,7 @@ def test_whole_training_step_matches_cpu_oracle(device):
             assert _rel(p.grad, q.grad) < 2e-3, (name, _rel(p.grad, q.grad))
             checked += 1
     assert checked > 40
+    monkeypatch.delenv("M3D_FOLD_MODULATIONS")
     # and the optimiser step runs and changes the weights
     l1 = step(batch)
     l2 = step(batch)
