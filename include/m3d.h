@@ -263,6 +263,21 @@ int m3d_conv_bwd_weight_bf16x3(const float* d_in, int cin, const float* d_dout, 
                                int64_t n, int64_t npad, float* d_dweight, void* d_ws, size_t ws_bytes,
                                void* stream);
 
+/* Batch normalisation in training mode (PDBatchNorm with batch statistics over all rows of this GPU,
+ * mosaic3d/src/models/networks/spconv_unet_v1m3_pdnorm.py:57-68; nn.BatchNorm1d, eps 1e-3, momentum 0.01): the two
+ * per-channel reductions over the [n, c] activations.  c a multiple of 4 (at most 1024), pointers 16-byte aligned,
+ * float64 accumulation, partial sums combined in a fixed order (deterministic).  The elementwise passes stay with
+ * the caller (y = (x - mean) * invstd * weight + bias;  dx from sum_dy / sum_dy_xmu as in synchronised batch norm).
+ *   m3d_bn_stats:            d_mean[c], d_var[c] = mean and BIASED variance of every column of d_x
+ *   m3d_bn_backward_reduce:  d_sum_dy[c] = sum_r dy[r][c];  d_sum_dy_xmu[c] = sum_r dy[r][c] * (x[r][c] - mean[c])
+ *   workspace: m3d_bn_workspace_bytes(n, c)
+ */
+size_t m3d_bn_workspace_bytes(int64_t n, int c);
+int m3d_bn_stats(const float* d_x, int64_t n, int c, float* d_mean, float* d_var, void* d_ws, size_t ws_bytes,
+                 void* stream);
+int m3d_bn_backward_reduce(const float* d_x, const float* d_dy, const float* d_mean, int64_t n, int c,
+                           float* d_sum_dy, float* d_sum_dy_xmu, void* d_ws, size_t ws_bytes, void* stream);
+
 /* Halo of a tile schedule (optional accelerator of m3d_conv_fwd_sf32 with terms = 2, meant for 3x3x3
  * submanifold maps of large levels).  For every tile of m3d_halo_tile_rows() = 256 schedule rows: the
  * distinct input rows its pairs reference (at most m3d_halo_cap() = 640; a tile with more is marked -1

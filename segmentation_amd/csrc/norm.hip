@@ -1,0 +1,165 @@
+// Per-channel reductions of batch normalisation in training mode (PDBatchNorm with batch statistics over all
+// rows of this GPU, mosaic3d/src/models/networks/spconv_unet_v1m3_pdnorm.py:57-68): the two passes over the [N, C]
+// activations that are pure column reductions.
+//
+//   m3d_bn_stats            mean[c], biased variance[c] of x[:, c]
+//   m3d_bn_backward_reduce  sum_dy[c] = sum_r dy[r][c],  sum_dy_xmu[c] = sum_r dy[r][c] * (x[r][c] - mean[c])
+//
+// Both are bound by HBM: a workgroup streams a contiguous range of rows as float4 (thread = fixed group of four
+// channels, consecutive threads = consecutive 16-byte pieces of a row), adds in float64, combines its row groups
+// through LDS and writes one partial per channel; a second, one-workgroup-per-channel-group pass adds the partials
+// in a fixed order (deterministic, no atomics).  The elementwise passes (normalise, input gradient) are left to the
+// caller.
+#include "common.h"
+
+namespace m3d {
+
+constexpr int kNormThreads = 256;
+constexpr int kNormMaxBlocks = 1024;
+
+// thread layout for c channels: c/4 float4 columns x R row groups, R = kNormThreads / (c/4)
+template <int NQ>
+__global__ __launch_bounds__(kNormThreads) void norm_partial_kernel(const float* __restrict__ x,
+                                                                    const float* __restrict__ dy,
+                                                                    const float* __restrict__ mean, int64_t n, int c,
+                                                                    int64_t rows_per_block,
+                                                                    double* __restrict__ partial) {
+  // NQ = 2 quantities per channel: (sum x, sum x^2) when dy == nullptr, else (sum dy, sum dy*(x - mean))
+  extern __shared__ double red[];  // [R][c][NQ]
+  const int c4 = c >> 2;
+  const int R = kNormThreads / c4;
+  const int col = threadIdx.x % c4, rg = threadIdx.x / c4;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r1 = r0 + rows_per_block < n ? r0 + rows_per_block : n;
+  double acc[4][NQ];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) acc[i][q] = 0.0;
+  if (rg < R) {
+    float4 mu = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (dy) mu = *reinterpret_cast<const float4*>(mean + 4 * col);
+#pragma unroll 4
+    for (int64_t r = r0 + rg; r < r1; r += R) {
+      const float4 v = *reinterpret_cast<const float4*>(x + r * c + 4 * col);
+      if (dy) {
+        const float4 g = *reinterpret_cast<const float4*>(dy + r * c + 4 * col);
+        acc[0][0] += g.x; acc[0][1] += (double)g.x * (double)(v.x - mu.x);
+        acc[1][0] += g.y; acc[1][1] += (double)g.y * (double)(v.y - mu.y);
+        acc[2][0] += g.z; acc[2][1] += (double)g.z * (double)(v.z - mu.z);
+        acc[3][0] += g.w; acc[3][1] += (double)g.w * (double)(v.w - mu.w);
+      } else {
+        acc[0][0] += v.x; acc[0][1] += (double)v.x * (double)v.x;
+        acc[1][0] += v.y; acc[1][1] += (double)v.y * (double)v.y;
+        acc[2][0] += v.z; acc[2][1] += (double)v.z * (double)v.z;
+        acc[3][0] += v.w; acc[3][1] += (double)v.w * (double)v.w;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) red[((int64_t)rg * c + 4 * col + i) * NQ + q] = acc[i][q];
+  }
+  __syncthreads();
+  // row groups are added in index order: one thread per (channel, quantity)
+  for (int e = threadIdx.x; e < c * NQ; e += kNormThreads) {
+    double s = 0.0;
+    for (int g = 0; g < R; ++g) s += red[(int64_t)g * c * NQ + e];
+    partial[(int64_t)blockIdx.x * c * NQ + e] = s;
+  }
+}
+
+// out0/out1 from the per-workgroup partials, added in workgroup order.
+//   stats:   out0 = mean = S1 / n, out1 = biased variance = S2 / n - mean^2 (clamped at 0)
+//   reduce:  out0 = sum_dy, out1 = sum_dy_xmu
+__global__ __launch_bounds__(256) void norm_final_kernel(const double* __restrict__ partial, int nblocks, int c,
+                                                         int64_t n, int stats, float* __restrict__ out0,
+                                                         float* __restrict__ out1) {
+  // a workgroup owns 8 channels = 16 consecutive doubles of every partial row; 16 groups of threads each add every
+  // 16th workgroup's partial, then the 16 group sums are added in index order
+  __shared__ double red[16][16];
+  const int e = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  const int ch0 = blockIdx.x * 8;
+  const bool live = ch0 + (e >> 1) < c;
+  double s = 0.0;
+  if (live)
+    for (int b = grp; b < nblocks; b += 16) s += partial[((int64_t)b * c + ch0) * 2 + e];
+  red[grp][e] = s;
+  __syncthreads();
+  if (threadIdx.x < 8 && ch0 + threadIdx.x < c) {
+    const int ch = ch0 + threadIdx.x;
+    double s0 = 0.0, s1 = 0.0;
+    for (int g = 0; g < 16; ++g) {
+      s0 += red[g][2 * threadIdx.x];
+      s1 += red[g][2 * threadIdx.x + 1];
+    }
+    if (stats) {
+      const double m = s0 / (double)n;
+      const double v = s1 / (double)n - m * m;
+      out0[ch] = (float)m;
+      out1[ch] = (float)(v > 0.0 ? v : 0.0);
+    } else {
+      out0[ch] = (float)s0;
+      out1[ch] = (float)s1;
+    }
+  }
+}
+
+static int norm_blocks(int64_t n, int c) {
+  // about 64 KB of input per workgroup, at most kNormMaxBlocks partials
+  int64_t rows = (int64_t)65536 / ((int64_t)c * 4);
+  if (rows < 8) rows = 8;
+  int64_t b = cdiv(n, rows);
+  if (b > kNormMaxBlocks) b = kNormMaxBlocks;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+static int norm_launch(const char* who, const float* x, const float* dy, const float* mean, int64_t n, int c,
+                       float* out0, float* out1, void* d_ws, size_t ws_bytes, hipStream_t stream) {
+  M3D_CHECK_ARG(n > 0 && x && out0 && out1, "%s: null pointer or no rows", who);
+  M3D_CHECK_ARG(c >= 4 && c % 4 == 0 && c <= 4 * kNormThreads, "%s: channel count %d must be a multiple of 4, at most %d",
+                who, c, 4 * kNormThreads);
+  M3D_CHECK_ARG(((uintptr_t)x & 15) == 0 && (dy == nullptr || ((uintptr_t)dy & 15) == 0) &&
+                    (mean == nullptr || ((uintptr_t)mean & 15) == 0),
+                "%s: pointers must be 16-byte aligned", who);
+  const int nb = norm_blocks(n, c);
+  const size_t need = (size_t)nb * c * 2 * sizeof(double);
+  if (d_ws == nullptr || ws_bytes < need) {
+    set_error("%s: workspace too small (%zu given, %zu needed)", who, ws_bytes, need);
+    return M3D_ENOSPC;
+  }
+  const int R = kNormThreads / (c / 4);
+  const size_t lds = (size_t)R * c * 2 * sizeof(double);  // <= 64 rows x 16 B x ... = 16 KB at most
+  const int64_t rows_per_block = cdiv(n, nb);
+  double* partial = static_cast<double*>(d_ws);
+  hipLaunchKernelGGL((norm_partial_kernel<2>), dim3(nb), dim3(kNormThreads), lds, stream, x, dy, mean, n, c,
+                     rows_per_block, partial);
+  hipLaunchKernelGGL(norm_final_kernel, dim3((unsigned)cdiv(c, 8)), dim3(256), 0, stream, partial, nb, c, n,
+                     dy == nullptr ? 1 : 0, out0, out1);
+  M3D_LAUNCH_CHECK();
+  return M3D_OK;
+}
+
+}  // namespace m3d
+
+using namespace m3d;
+
+extern "C" size_t m3d_bn_workspace_bytes(int64_t n, int c) {
+  if (n <= 0 || c <= 0) return 256;
+  return align_up((size_t)norm_blocks(n, c) * c * 2 * sizeof(double));
+}
+
+extern "C" int m3d_bn_stats(const float* d_x, int64_t n, int c, float* d_mean, float* d_var, void* d_ws,
+                            size_t ws_bytes, void* stream) {
+  return norm_launch("m3d_bn_stats", d_x, nullptr, nullptr, n, c, d_mean, d_var, d_ws, ws_bytes,
+                     static_cast<hipStream_t>(stream));
+}
+
+extern "C" int m3d_bn_backward_reduce(const float* d_x, const float* d_dy, const float* d_mean, int64_t n, int c,
+                                      float* d_sum_dy, float* d_sum_dy_xmu, void* d_ws, size_t ws_bytes,
+                                      void* stream) {
+  M3D_CHECK_ARG(d_dy && d_mean, "m3d_bn_backward_reduce: null pointer");
+  return norm_launch("m3d_bn_backward_reduce", d_x, d_dy, d_mean, n, c, d_sum_dy, d_sum_dy_xmu, d_ws, ws_bytes,
+                     static_cast<hipStream_t>(stream));
+}

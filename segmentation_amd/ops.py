@@ -454,6 +454,36 @@ def conv_bwd_weight(x, dout, sched, k, precision="f32"):
     return dw[:cout, :, :cin] if (pin or pout) else dw
 
 
+def bn_stats(x):
+    """Per-channel mean and biased variance of x [n, c] f32 (m3d_bn_stats); c a multiple of 4."""
+    lib = _lib.load()
+    _need_cuda(x)
+    assert x.dtype == torch.float32 and x.dim() == 2 and x.is_contiguous()
+    n, c = x.shape
+    mean = torch.empty((c,), dtype=torch.float32, device=x.device)
+    var = torch.empty((c,), dtype=torch.float32, device=x.device)
+    ws = _workspace(lib.m3d_bn_workspace_bytes(n, c), x.device)
+    rc = lib.m3d_bn_stats(_ptr(x), n, c, _ptr(mean), _ptr(var), _ptr(ws), ws.numel(), _stream())
+    _lib.check(rc, "m3d_bn_stats")
+    return mean, var
+
+
+def bn_backward_reduce(x, dy, mean):
+    """sum_dy[c], sum_dy_xmu[c] = column sums of dy and of dy * (x - mean) (m3d_bn_backward_reduce)."""
+    lib = _lib.load()
+    _need_cuda(x, dy, mean)
+    assert x.dtype == dy.dtype == mean.dtype == torch.float32 and x.is_contiguous() and dy.is_contiguous()
+    assert x.shape == dy.shape and mean.numel() == x.shape[1]
+    n, c = x.shape
+    sum_dy = torch.empty((c,), dtype=torch.float32, device=x.device)
+    sum_dy_xmu = torch.empty((c,), dtype=torch.float32, device=x.device)
+    ws = _workspace(lib.m3d_bn_workspace_bytes(n, c), x.device)
+    rc = lib.m3d_bn_backward_reduce(_ptr(x), _ptr(dy), _ptr(mean), n, c, _ptr(sum_dy), _ptr(sum_dy_xmu), _ptr(ws),
+                                    ws.numel(), _stream())
+    _lib.check(rc, "m3d_bn_backward_reduce")
+    return sum_dy, sum_dy_xmu
+
+
 def argmax_rows(logits, n_classes):
     lib = _lib.load()
     _need_cuda(logits)

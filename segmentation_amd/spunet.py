@@ -66,6 +66,40 @@ class PDBatchNorm(nn.Module):
         return bn(feat) * (1.0 + scale) + shift
 
 
+_BN_KERNEL_ROWS = int(os.environ.get("M3D_BN_KERNEL_ROWS", "20000"))
+_COUNTS = {}
+
+
+class _BatchNormTrainFn(torch.autograd.Function):
+    """Batch-statistics normalisation of x [n, c] with the column reductions on the library's kernels
+    (m3d_bn_stats, m3d_bn_backward_reduce) and torch's elementwise kernels of synchronised batch norm for the
+    rest.  Returns (y, mean, biased variance); only y is differentiable."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps):
+        x = x.contiguous()
+        mean, var = ops.bn_stats(x)
+        invstd = torch.rsqrt(var + eps)
+        y = torch.batch_norm_elemt(x, weight, bias, mean, invstd, eps)
+        ctx.save_for_backward(x, weight, mean, invstd)
+        ctx.mark_non_differentiable(mean, var)
+        return y, mean, var
+
+    @staticmethod
+    def backward(ctx, dy, _dmean, _dvar):
+        x, weight, mean, invstd = ctx.saved_tensors
+        dy = dy.contiguous()
+        sum_dy, sum_dy_xmu = ops.bn_backward_reduce(x, dy, mean)
+        key = (x.device, x.shape[0])
+        count = _COUNTS.get(key)
+        if count is None:
+            if len(_COUNTS) > 64:
+                _COUNTS.clear()
+            count = _COUNTS[key] = torch.tensor([x.shape[0]], dtype=torch.int32, device=x.device)
+        dx = torch.batch_norm_backward_elemt(dy, x, mean, invstd, weight, sum_dy, sum_dy_xmu, count)
+        return dx, sum_dy_xmu * invstd, sum_dy, None
+
+
 def _batch_norm_with(bn, x, weight, bias):
     """nn.BatchNorm1d.forward of `bn` with another affine pair: same statistics, running-average update and
     batch counter."""
@@ -76,6 +110,15 @@ def _batch_norm_with(bn, x, weight, bias):
             factor = 1.0 / float(bn.num_batches_tracked)
     use_batch_stats = bn.training or (bn.running_mean is None and bn.running_var is None)
     keep_running = not bn.training or bn.track_running_stats
+    n = x.shape[0]
+    if (use_batch_stats and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.shape[1] % 4 == 0
+            and x.shape[1] <= 1024 and _BN_KERNEL_ROWS and n >= _BN_KERNEL_ROWS):
+        y, mean, var = _BatchNormTrainFn.apply(x, weight, bias, bn.eps)
+        if keep_running and bn.running_mean is not None:
+            with torch.no_grad():
+                bn.running_mean.lerp_(mean, factor)
+                bn.running_var.lerp_(var * (n / (n - 1.0)), factor)
+        return y
     return F.batch_norm(x, bn.running_mean if keep_running else None, bn.running_var if keep_running else None,
                         weight, bias, use_batch_stats, factor, bn.eps)
 
