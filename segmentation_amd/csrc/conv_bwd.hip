@@ -109,13 +109,24 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_kernel(BwdWArgs a) {
 // (c, h) holds channel c of rows t + 8h .. t + 8h + 7 for both operands (eight 128-byte row segments each, straight
 // from global memory), splits every value into hi = bf16(v) and lo = bf16(v - hi) in registers and forms
 // hi*hi + hi*lo + lo*hi in the f32 accumulator.  One sixteenth of the matrix-pipe time of the f32 instruction per
-// product; what remains is the gather.
+// product; what remains is the latency of the gather (row indices, then the rows), so the loop is a two-stage
+// pipeline over the wave's items (an item = sixteen rows of a tile that has the offset): while item i is split and
+// multiplied, the rows of item i + 1 and the row indices of item i + 2 are in flight.  The tile masks are read
+// with wave-uniform addresses (scalar loads, which do not queue behind the vector loads).
 template <int TA, int TB>
+struct BwdItem {
+  int64_t tile;
+  int half;  // 0 or 1: rows 0..15 / 16..31 of the tile
+  bool ok;
+};
+
+template <int TA, int TB, bool DENSE>
 __global__ __launch_bounds__(256) void conv_bwd_weight_split_kernel(BwdWArgs a) {
   const int k = blockIdx.x, split = blockIdx.z;
   const int tiles_ci = a.cin / (32 * TB);
   const int co0 = (blockIdx.y / tiles_ci) * 32 * TA, ci0 = (blockIdx.y % tiles_ci) * 32 * TB;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int c = lane & 31, h = lane >> 5;
   const int64_t ntile = a.npad / 32;
   const int64_t per = (ntile + a.nsplit - 1) / a.nsplit;
@@ -129,55 +140,118 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_split_kernel(BwdWArgs a) 
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   const float* dout_c = a.dout + co0 + c;
   const float* in_c = a.in + ci0 + c;
-  for (int64_t tile = tile0 + wave; tile < tile1; tile += 4) {
-    if (a.tile_mask && !((a.tile_mask[tile] >> k) & 1u)) continue;
+  using Item = BwdItem<TA, TB>;
+  struct Idx { int jj[8], ii[8]; };
+  struct Raw { float av[TA][8], bv[TB][8]; unsigned ok; };  // ok: bit i = row i of the lane's eight is a pair
+
+  auto active_from = [&](int64_t t) {  // first tile >= t of this wave's sequence that has offset k
+    if (!DENSE)
+      while (t < tile1 && !((a.tile_mask[t] >> k) & 1u)) t += 4;
+    return t;
+  };
+  auto next_item = [&](const Item& it) {
+    Item n;
+    if (it.half == 0) {
+      n.tile = it.tile; n.half = 1; n.ok = it.ok;
+    } else {
+      n.tile = it.ok ? active_from(it.tile + 4) : it.tile; n.half = 0; n.ok = it.ok && n.tile < tile1;
+    }
+    return n;
+  };
+  // Loads are issued for every item, valid or not (an item past the end reads the indices of the range's last tile
+  // and none of the rows): the number of loads between an issue and its use is then the same on every path, and the
+  // waits in front of the matrix work count exactly the younger loads.
+  auto load_idx = [&](Idx& ix, const Item& it) {
+    const int64_t tile = it.tile < tile1 ? it.tile : tile1 - 1;
+    const int64_t t0 = tile * 32 + 16 * it.half + 8 * h;
+    int4 j0, j1, i0, i1;
+    if (DENSE) {
+      const int b = (int)t0;
+      j0 = make_int4(b, b + 1, b + 2, b + 3);
+      j1 = make_int4(b + 4, b + 5, b + 6, b + 7);
+      const int lim = (int)a.n;
+      j0.x = j0.x < lim ? j0.x : -1; j0.y = j0.y < lim ? j0.y : -1; j0.z = j0.z < lim ? j0.z : -1; j0.w = j0.w < lim ? j0.w : -1;
+      j1.x = j1.x < lim ? j1.x : -1; j1.y = j1.y < lim ? j1.y : -1; j1.z = j1.z < lim ? j1.z : -1; j1.w = j1.w < lim ? j1.w : -1;
+      i0 = j0;
+      i1 = j1;
+    } else {
+      j0 = *reinterpret_cast<const int4*>(a.out_row + t0);
+      j1 = *reinterpret_cast<const int4*>(a.out_row + t0 + 4);
+      i0 = *reinterpret_cast<const int4*>(a.nbr + (int64_t)k * a.npad + t0);
+      i1 = *reinterpret_cast<const int4*>(a.nbr + (int64_t)k * a.npad + t0 + 4);
+    }
+    const int dead = it.ok ? 0 : -1;  // an item past the end: every row index becomes negative
+    ix.jj[0] = j0.x | dead; ix.jj[1] = j0.y | dead; ix.jj[2] = j0.z | dead; ix.jj[3] = j0.w | dead;
+    ix.jj[4] = j1.x | dead; ix.jj[5] = j1.y | dead; ix.jj[6] = j1.z | dead; ix.jj[7] = j1.w | dead;
+    ix.ii[0] = i0.x; ix.ii[1] = i0.y; ix.ii[2] = i0.z; ix.ii[3] = i0.w;
+    ix.ii[4] = i1.x; ix.ii[5] = i1.y; ix.ii[6] = i1.z; ix.ii[7] = i1.w;
+  };
+  // Rows without a pair are read from row 0 and dropped when the operands are split: every load is issued
+  // unconditionally (no branch per row), and a missing pair costs a cache hit.
+  auto load_rows = [&](Raw& r, const Idx& ix) {
+    r.ok = 0;
 #pragma unroll
-    for (int s = 0; s < 32; s += 16) {
-      const int64_t t0 = tile * 32 + s + 8 * h;
-      int jj[8], ii[8];
-      if (a.nbr) {
-        const int4 j0 = *reinterpret_cast<const int4*>(a.out_row + t0);
-        const int4 j1 = *reinterpret_cast<const int4*>(a.out_row + t0 + 4);
-        const int4 i0 = *reinterpret_cast<const int4*>(a.nbr + (int64_t)k * a.npad + t0);
-        const int4 i1 = *reinterpret_cast<const int4*>(a.nbr + (int64_t)k * a.npad + t0 + 4);
-        jj[0] = j0.x; jj[1] = j0.y; jj[2] = j0.z; jj[3] = j0.w; jj[4] = j1.x; jj[5] = j1.y; jj[6] = j1.z; jj[7] = j1.w;
-        ii[0] = i0.x; ii[1] = i0.y; ii[2] = i0.z; ii[3] = i0.w; ii[4] = i1.x; ii[5] = i1.y; ii[6] = i1.z; ii[7] = i1.w;
-      } else {
+    for (int i = 0; i < 8; ++i) {
+      const bool ok = ix.jj[i] >= 0 && ix.ii[i] >= 0;
+      r.ok |= ok ? (1u << i) : 0u;
+      const int64_t jr = ok ? ix.jj[i] : 0, ir = ok ? ix.ii[i] : 0;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) jj[i] = ii[i] = t0 + i < a.n ? (int)(t0 + i) : -1;
-      }
-      float av[TA][8], bv[TB][8];
+      for (int x = 0; x < TA; ++x) r.av[x][i] = dout_c[jr * a.cout + x * 32];
+#pragma unroll
+      for (int x = 0; x < TB; ++x) r.bv[x][i] = in_c[ir * a.cin + x * 32];
+    }
+  };
+  auto multiply = [&](const Raw& r) {
+    bf16x8 ahi[TA], alo[TA], bhi[TB], blo[TB];
+#pragma unroll
+    for (int x = 0; x < TA; ++x)
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        const bool ok = jj[i] >= 0 && ii[i] >= 0;
-#pragma unroll
-        for (int x = 0; x < TA; ++x) av[x][i] = ok ? dout_c[(int64_t)jj[i] * a.cout + x * 32] : 0.f;
-#pragma unroll
-        for (int x = 0; x < TB; ++x) bv[x][i] = ok ? in_c[(int64_t)ii[i] * a.cin + x * 32] : 0.f;
+        const float v = (r.ok >> i) & 1u ? r.av[x][i] : 0.f;  // one zero operand is enough
+        ahi[x][i] = (__bf16)v;
+        alo[x][i] = (__bf16)(v - (float)ahi[x][i]);
       }
-      bf16x8 ahi[TA], alo[TA], bhi[TB], blo[TB];
 #pragma unroll
-      for (int x = 0; x < TA; ++x)
+    for (int x = 0; x < TB; ++x)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          ahi[x][i] = (__bf16)av[x][i];
-          alo[x][i] = (__bf16)(av[x][i] - (float)ahi[x][i]);
-        }
+      for (int i = 0; i < 8; ++i) {
+        bhi[x][i] = (__bf16)r.bv[x][i];
+        blo[x][i] = (__bf16)(r.bv[x][i] - (float)bhi[x][i]);
+      }
 #pragma unroll
-      for (int x = 0; x < TB; ++x)
+    for (int x = 0; x < TA; ++x)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          bhi[x][i] = (__bf16)bv[x][i];
-          blo[x][i] = (__bf16)(bv[x][i] - (float)bhi[x][i]);
-        }
-#pragma unroll
-      for (int x = 0; x < TA; ++x)
-#pragma unroll
-        for (int y = 0; y < TB; ++y) {
-          acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo[x], bhi[y], acc[x][y], 0, 0, 0);
-          acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[x], blo[y], acc[x][y], 0, 0, 0);
-          acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[x], bhi[y], acc[x][y], 0, 0, 0);
-        }
+      for (int y = 0; y < TB; ++y) {
+        acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo[x], bhi[y], acc[x][y], 0, 0, 0);
+        acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[x], blo[y], acc[x][y], 0, 0, 0);
+        acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[x], bhi[y], acc[x][y], 0, 0, 0);
+      }
+  };
+
+  Item cur;
+  cur.tile = active_from(tile0 + wave);
+  cur.half = 0;
+  cur.ok = cur.tile < tile1;
+  if (cur.ok) {  // wave-uniform
+    Idx ixa, ixb;
+    Raw ra, rb;
+    load_idx(ixa, cur);
+    load_rows(ra, ixa);
+    Item nxt = next_item(cur);
+    load_idx(ixb, nxt);
+    while (true) {
+      // rows of the current item -> ra (in flight); indices of the next item -> ixb (in flight)
+      const Item n2 = next_item(nxt);
+      load_rows(rb, ixb);
+      load_idx(ixa, n2);
+      multiply(ra);
+      if (!nxt.ok) break;
+      const Item n3 = next_item(n2);
+      load_rows(ra, ixa);
+      load_idx(ixb, n3);
+      multiply(rb);
+      if (!n2.ok) break;
+      nxt = n3;
     }
   }
   bwd_weight_store<TA, TB>(a, acc, k, split, co0, ci0, lane, wave, c, h);
@@ -245,9 +319,12 @@ static int conv_bwd_weight_launch(const char* who, bool split_products, const fl
   dim3 grid((unsigned)k, (unsigned)tiles, (unsigned)nsplit);
 #define M3D_BW(TA_, TB_)                                                                                      \
   if (ta == TA_ && tb == TB_) {                                                                                \
-    if (split_products)                                                                                        \
-      hipLaunchKernelGGL((conv_bwd_weight_split_kernel<TA_, TB_>), grid, dim3(256), 0, stream, a);             \
-    else                                                                                                       \
+    if (split_products) {                                                                                      \
+      if (d_nbr)                                                                                               \
+        hipLaunchKernelGGL((conv_bwd_weight_split_kernel<TA_, TB_, false>), grid, dim3(256), 0, stream, a);    \
+      else                                                                                                     \
+        hipLaunchKernelGGL((conv_bwd_weight_split_kernel<TA_, TB_, true>), grid, dim3(256), 0, stream, a);     \
+    } else                                                                                                     \
       hipLaunchKernelGGL((conv_bwd_weight_kernel<TA_, TB_>), grid, dim3(256), 0, stream, a);                   \
   }
   M3D_BW(1, 1) M3D_BW(1, 2) M3D_BW(1, 3) M3D_BW(2, 1) M3D_BW(2, 2) M3D_BW(2, 3) M3D_BW(3, 1) M3D_BW(3, 2) M3D_BW(3, 3)
