@@ -245,10 +245,20 @@ class SpUNet(nn.Module):
         sizes = [m.modulation[1].out_features // 2 for m in norms]
         lin = [m.modulation[1] for m in norms]
         act = F.silu(context.to(dtype))
-        shift = F.linear(act, torch.cat([l.weight[:c] for l, c in zip(lin, sizes)]),
-                         torch.cat([l.bias[:c] for l, c in zip(lin, sizes)]))[0]
-        scale = F.linear(act, torch.cat([l.weight[c:] for l, c in zip(lin, sizes)]),
-                         torch.cat([l.bias[c:] for l, c in zip(lin, sizes)]))[0]
+        # one product over the whole weights ([shift rows; scale rows] per norm, v1m3:66), then two gathers that
+        # collect all shifts and all scales: slicing every weight instead would cost a zero fill and a copy per slice
+        # in the backward pass
+        mod = F.linear(act, torch.cat([l.weight for l in lin]), torch.cat([l.bias for l in lin]))[0]
+        picks = self.__dict__.get("_mod_picks")
+        if picks is None or picks[0].device != mod.device:
+            shift_idx, scale_idx, base = [], [], 0
+            for c in sizes:
+                shift_idx.append(torch.arange(base, base + c))
+                scale_idx.append(torch.arange(base + c, base + 2 * c))
+                base += 2 * c
+            picks = (torch.cat(shift_idx).to(mod.device), torch.cat(scale_idx).to(mod.device))
+            self.__dict__["_mod_picks"] = picks
+        shift, scale = mod.index_select(0, picks[0]), mod.index_select(0, picks[1])
         bns = [m.pick(condition) for m in norms]
         gain = 1.0 + scale
         weight = torch.cat([b.weight for b in bns]) * gain
