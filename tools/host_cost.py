@@ -1,4 +1,5 @@
-import sys, time; sys.path.insert(0, "/root/repo")
+"""Host-side enqueue time of the map and backbone phases against their GPU time, and a cProfile of five forward passes."""
+import os, sys, time; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, cProfile, pstats
 import bench
 from segmentation_amd import ops, scenes

@@ -1,6 +1,6 @@
 """Time of the pattern schedule (m3d_build_schedule, mode 3) and the submanifold map per resolution level."""
-import sys
-sys.path.insert(0, "/root/repo")
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import bench
 from segmentation_amd import ops, scenes
