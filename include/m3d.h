@@ -303,6 +303,12 @@ int m3d_split_f32(const float* d_in, int64_t n, int c, int terms, void* d_out, v
 size_t m3d_conv_packed_weight_bytes(int cout, int k, int cin, int precision);
 int m3d_conv_pack_weight(const float* d_weight_ref, int cout, int k, int cin, int precision,
                          void* d_out, void* stream);
+/* The weight of the layer's input-gradient convolution (see "Training step" above), packed straight from the
+ * layer's own [cout, k, cin] weight: W'[ci][k'][co] = W[co][flip ? k - 1 - k' : k'][ci] (flip != 0 for submanifold
+ * maps, whose transposed map is the same map with the offsets reversed).  The result is a packed weight with cin
+ * output and cout input channels: m3d_conv_packed_weight_bytes(cin, k, cout, precision) bytes. */
+int m3d_conv_pack_weight_transposed(const float* d_weight_ref, int cout, int k, int cin, int flip, int precision,
+                                    void* d_out, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Open-vocabulary head.  Replaces clip_feat = features[v2p_map]

@@ -57,6 +57,7 @@ SIGNATURES = {
     "m3d_split_f32": (_int, [_vp, _i64, _int, _int, _vp, _vp]),
     "m3d_conv_packed_weight_bytes": (_sz, [_int, _int, _int, _int]),
     "m3d_conv_pack_weight": (_int, [_vp, _int, _int, _int, _int, _vp, _vp]),
+    "m3d_conv_pack_weight_transposed": (_int, [_vp, _int, _int, _int, _int, _int, _vp, _vp]),
     "m3d_argmax_rows": (_int, [_vp, _i64, _int, _i64, _vp, _vp]),
     "m3d_gather_labels": (_int, [_vp, _vp, _i64, _vp, _vp]),
     "m3d_avgpool_fwd": (_int, [_vp, _int, _vp, _int, _i64, _i64, _vp, _vp, _vp]),

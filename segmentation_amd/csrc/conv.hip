@@ -559,15 +559,18 @@ __global__ void split_f32_kernel(const float* __restrict__ in, int64_t n, int c,
 // Reference layout [Cout][k][Cin] f32 -> kernel layouts.
 //   terms == 0: [k][Cout][Cin] f32
 //   terms == 2/3: [k][Cout][Cin/32][terms][32] bf16 (term t = bf16 rounding of the remainder)
+// transposed != 0: the packed weight is W'[o][k][c] = w[c][flip ? kvol - 1 - k : k][o] (w has the reference layout
+// [cin'][kvol][cout'] of the layer it came from; cout/cin below are those of W'): the weight of the input-gradient
+// convolution, formed without a transposed copy of w.
 __global__ void pack_weight_kernel(const float* __restrict__ w, int cout, int kvol, int cin, int terms,
-                                   void* __restrict__ out) {
+                                   int transposed, int flip, void* __restrict__ out) {
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t total = (int64_t)cout * kvol * cin;
   if (e >= total) return;
   const int c = (int)(e % cin);
   const int k = (int)((e / cin) % kvol);
   const int o = (int)(e / ((int64_t)cin * kvol));
-  float x = w[e];
+  float x = transposed ? w[((int64_t)c * kvol + (flip ? kvol - 1 - k : k)) * cout + o] : w[e];
   if (terms == 0) {
     static_cast<float*>(out)[((int64_t)k * cout + o) * cin + c] = x;
     return;
@@ -1026,16 +1029,28 @@ extern "C" size_t m3d_conv_packed_weight_bytes(int cout, int k, int cin, int pre
   return elems * 2 * (precision == M3D_PREC_BF16X3 ? 2 : 3);
 }
 
-extern "C" int m3d_conv_pack_weight(const float* d_weight_ref, int cout, int k, int cin, int precision,
-                                    void* d_out, void* stream_) {
+static int pack_weight_launch(const char* who, const float* d_weight_ref, int cout, int k, int cin, int precision,
+                              int transposed, int flip, void* d_out, void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
-  M3D_CHECK_ARG(d_weight_ref && d_out && cout > 0 && k > 0 && cin > 0, "m3d_conv_pack_weight: bad arguments");
-  M3D_CHECK_ARG(precision >= 0 && precision <= 2, "m3d_conv_pack_weight: unknown precision %d", precision);
+  M3D_CHECK_ARG(d_weight_ref && d_out && cout > 0 && k > 0 && cin > 0, "%s: bad arguments", who);
+  M3D_CHECK_ARG(precision >= 0 && precision <= 2, "%s: unknown precision %d", who, precision);
   const bool mfma_ok = cin % 32 == 0 && cout % 32 == 0;
   const int terms = (precision == M3D_PREC_F32 || !mfma_ok) ? 0 : (precision == M3D_PREC_BF16X3 ? 2 : 3);
   const int64_t total = (int64_t)cout * k * cin;
   hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, stream, d_weight_ref,
-                     cout, k, cin, terms, d_out);
+                     cout, k, cin, terms, transposed, flip, d_out);
   M3D_LAUNCH_CHECK();
   return M3D_OK;
+}
+
+extern "C" int m3d_conv_pack_weight(const float* d_weight_ref, int cout, int k, int cin, int precision,
+                                    void* d_out, void* stream) {
+  return pack_weight_launch("m3d_conv_pack_weight", d_weight_ref, cout, k, cin, precision, 0, 0, d_out, stream);
+}
+
+extern "C" int m3d_conv_pack_weight_transposed(const float* d_weight_ref, int cout, int k, int cin, int flip,
+                                               int precision, void* d_out, void* stream) {
+  // the packed weight has cin output and cout input channels
+  return pack_weight_launch("m3d_conv_pack_weight_transposed", d_weight_ref, cin, k, cout, precision, 1, flip != 0,
+                            d_out, stream);
 }

@@ -266,8 +266,10 @@ class PackedWeight:
     precision: str
 
 
-def pack_weight(weight, precision="f32", device=None):
-    """Reference layout [Cout, k0, k1, k2, Cin] (or [Cout, K, Cin]) f32 -> PackedWeight on `device`."""
+def pack_weight(weight, precision="f32", device=None, transposed=False, flip=False):
+    """Reference layout [Cout, k0, k1, k2, Cin] (or [Cout, K, Cin]) f32 -> PackedWeight on `device`.
+    transposed=True packs the weight of the layer's input-gradient convolution instead, W'[ci][k'][co] =
+    W[co][K-1-k' if flip else k'][ci] (a PackedWeight with Cin outputs and Cout inputs), in the same single pass."""
     lib = _lib.load()
     w = weight.detach().float()
     cout, cin = w.shape[0], w.shape[-1]
@@ -277,6 +279,12 @@ def pack_weight(weight, precision="f32", device=None):
         w = w.to(device)
     _need_cuda(w)
     prec = PRECISION[precision]
+    if transposed:
+        nbytes = lib.m3d_conv_packed_weight_bytes(cin, k, cout, prec)
+        out = torch.empty((nbytes,), dtype=torch.uint8, device=w.device)
+        rc = lib.m3d_conv_pack_weight_transposed(_ptr(w), cout, k, cin, int(bool(flip)), prec, _ptr(out), _stream())
+        _lib.check(rc, "m3d_conv_pack_weight_transposed")
+        return PackedWeight(out, k, cin, cout, precision)
     nbytes = lib.m3d_conv_packed_weight_bytes(cout, k, cin, prec)
     out = torch.empty((nbytes,), dtype=torch.uint8, device=w.device)
     rc = lib.m3d_conv_pack_weight(_ptr(w), cout, k, cin, prec, _ptr(out), _stream())

@@ -327,10 +327,7 @@ class _SparseConvFn(torch.autograd.Function):
         k = weight.numel() // (cout * cin)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            wt = weight.detach().reshape(cout, k, cin).permute(2, 1, 0)  # [Cin, k, Cout]
-            if flip:
-                wt = wt.flip(1)
-            wt = ops.pack_weight(wt.contiguous(), precision)
+            wt = ops.pack_weight(weight, precision, transposed=True, flip=flip)  # W'[ci][k'][co], one pass
             dx = ops.conv_fwd(_maybe_split(dout, wt), wt, sched_back, n_in)
         if ctx.needs_input_grad[1]:
             dw = ops.conv_bwd_weight(feats, dout, sched_fwd, k,

@@ -264,3 +264,18 @@ def test_whole_training_step_matches_cpu_oracle(device, monkeypatch):
     l1 = step(batch)
     l2 = step(batch)
     assert np.isfinite(l1) and np.isfinite(l2)
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16x3", "bf16x6"])
+@pytest.mark.parametrize("cout,k,cin,flip", [(64, 27, 32, True), (96, 8, 128, False), (32, 1, 96, False), (32, 27, 3, True)])
+def test_transposed_weight_packing_equals_packing_the_transposed_weight(device, precision, cout, k, cin, flip):
+    """m3d_conv_pack_weight_transposed forms the input-gradient weight W'[ci][k'][co] = W[co][k-1-k' | k'][ci] in
+    one pass; its bytes must be those of m3d_conv_pack_weight on an explicitly transposed (and flipped) copy."""
+    w = torch.randn(cout, k, cin, generator=torch.Generator().manual_seed(cout + k + cin)).to(device)
+    wt = w.permute(2, 1, 0)
+    if flip:
+        wt = wt.flip(1)
+    a = ops.pack_weight(wt.contiguous(), precision)
+    b = ops.pack_weight(w, precision, transposed=True, flip=flip)
+    assert (a.k, a.cout, a.cin) == (b.k, b.cout, b.cin) == (k, cin, cout)
+    assert torch.equal(a.data, b.data)
