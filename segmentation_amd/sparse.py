@@ -290,7 +290,7 @@ class SparseConvolution(SparseModule):
                                 x.indice_dict, x.benchmark)
 
 
-_SPLIT_FIRST_ROWS = int(os.environ.get("M3D_SPLIT_FIRST_ROWS", "5000"))
+_SPLIT_FIRST_ROWS = int(os.environ.get("M3D_SPLIT_FIRST_ROWS", "1500"))
 
 
 def _maybe_split(x, w):
