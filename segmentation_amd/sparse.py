@@ -295,8 +295,10 @@ _SPLIT_FIRST_ROWS = int(os.environ.get("M3D_SPLIT_FIRST_ROWS", "1500"))
 
 def _maybe_split(x, w):
     """Large f32 activations of a bf16x3 convolution are split into the two-term format once, so that the
-    convolution runs on the LDS-DMA kernel; small ones are split inside the register-staged kernel."""
-    if w.precision == "bf16x3" and x.shape[1] % 32 == 0 and _SPLIT_FIRST_ROWS and x.shape[0] >= _SPLIT_FIRST_ROWS:
+    convolution runs on the LDS-DMA kernel (which needs both channel counts to be multiples of 32); small ones are
+    split inside the register-staged kernel."""
+    if (w.precision == "bf16x3" and w.cin % 32 == 0 and w.cout % 32 == 0 and x.shape[1] == w.cin and _SPLIT_FIRST_ROWS
+            and x.shape[0] >= _SPLIT_FIRST_ROWS):
         return ops.split_f32(x, 2)
     return x
 
