@@ -59,13 +59,15 @@ def cpu_baseline(model, cfg, scene, emb):
         P[k[len("backbone."):] if k.startswith("backbone.") else k] = v.detach().float().cpu()
     n = scene["coord"].shape[0]
     off = np.array([0, n], dtype=np.int64)
+    passes = 4  # about 12 s on 16 cores: a bounded sample of the same workload
     t0 = time.perf_counter()
-    sp, out = ospunet.spunet_from_points(P, cfg, scene["coord"], scene["feat"], off, GRID)
-    pred = oracle.head_predict(out, sp["v2p_map"], emb)
+    for _ in range(passes):
+        sp, out = ospunet.spunet_from_points(P, cfg, scene["coord"], scene["feat"], off, GRID)
+        pred = oracle.head_predict(out, sp["v2p_map"], emb)
     dt = time.perf_counter() - t0
     n0 = sp["voxel_coords"].shape[0]
-    return dict(value=n0 / dt, unit="voxels/s", cores=cores, kind="port",
-                sample=f"1 pass over one synthetic scene, N0={n0} voxels / {n} points, {dt:.1f} s wall"), pred
+    return dict(value=passes * n0 / dt, unit="voxels/s", cores=cores, kind="port",
+                sample=f"{passes} passes over one synthetic scene, N0={n0} voxels / {n} points, {dt:.1f} s wall"), pred
 
 
 def main():
