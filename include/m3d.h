@@ -278,6 +278,18 @@ int m3d_bn_stats(const float* d_x, int64_t n, int c, float* d_mean, float* d_var
 int m3d_bn_backward_reduce(const float* d_x, const float* d_dy, const float* d_mean, int64_t n, int c,
                            float* d_sum_dy, float* d_sum_dy_xmu, void* d_ws, size_t ws_bytes, void* stream);
 
+/* m3d_bn_stats without any allocation and without a workspace argument: the per-workgroup partial sums live in a
+ * fixed 4 MiB array inside the library's code object (every GPU the library runs on holds its own copy until the
+ * process ends).  Has no counterpart in the reference; it is for callers that cannot allocate device memory: code
+ * under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  Same kernels, same summation
+ * order and bit-identical results as m3d_bn_stats.  Limit: m3d_bn_workspace_bytes(n, c) must not exceed
+ * m3d_bn_stats_static_max_bytes() (any n for c <= 256); beyond it the call fails with M3D_ENOSPC and launches
+ * nothing.  The device that `stream` belongs to must be current.  All calls on one GPU share that GPU's array:
+ * calls that overlap on one GPU (two streams, two threads) race; calls on one stream are ordered and safe.
+ * Nothing in the array has to start at zero (every partial a call reads is written by that call first). */
+size_t m3d_bn_stats_static_max_bytes(void);
+int m3d_bn_stats_static(const float* d_x, int64_t n, int c, float* d_mean, float* d_var, void* stream);
+
 /* Halo of a tile schedule (optional accelerator of m3d_conv_fwd_sf32 with terms = 2, meant for 3x3x3
  * submanifold maps of large levels).  For every tile of m3d_halo_tile_rows() = 256 schedule rows: the
  * distinct input rows its pairs reference (at most m3d_halo_cap() = 640; a tile with more is marked -1

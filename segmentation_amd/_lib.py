@@ -49,6 +49,8 @@ SIGNATURES = {
     "m3d_conv_bwd_weight_bf16x3": (_int, [_vp, _int, _vp, _int, _int, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _sz, _vp]),
     "m3d_bn_workspace_bytes": (_sz, [_i64, _int]),
     "m3d_bn_stats": (_int, [_vp, _i64, _int, _vp, _vp, _vp, _sz, _vp]),
+    "m3d_bn_stats_static_max_bytes": (_sz, []),
+    "m3d_bn_stats_static": (_int, [_vp, _i64, _int, _vp, _vp, _vp]),
     "m3d_bn_backward_reduce": (_int, [_vp, _vp, _vp, _i64, _int, _vp, _vp, _vp, _sz, _vp]),
     "m3d_halo_cap": (_int, []),
     "m3d_halo_tile_rows": (_int, []),

@@ -12,10 +12,18 @@
 // caller.
 #include "common.h"
 
+#include <mutex>
+
 namespace m3d {
 
 constexpr int kNormThreads = 256;
 constexpr int kNormMaxBlocks = 1024;
+
+// Partial sums of m3d_bn_stats_static: a fixed array inside the code object, one copy per GPU, held until the
+// process ends.  4 MiB = kNormMaxBlocks workgroups x 256 channels x 2 quantities x 8 bytes.  Host code never uses this
+// name as an address: it asks the runtime for the device address once per device (static_scratch below).
+constexpr size_t kStaticScratchBytes = (size_t)kNormMaxBlocks * 256 * 2 * sizeof(double);
+static __device__ __align__(256) double scratch[kStaticScratchBytes / sizeof(double)];
 
 // thread layout for c channels: c/4 float4 columns x R row groups, R = kNormThreads / (c/4)
 template <int NQ>
@@ -141,6 +149,25 @@ static int norm_launch(const char* who, const float* x, const float* dy, const f
   return M3D_OK;
 }
 
+// Device address of `scratch` on the current device, looked up once per device.
+static int static_scratch(const char* who, double** out) {
+  constexpr int kMaxDevices = 64;
+  static std::mutex mu;
+  static double* ptr[kMaxDevices] = {};
+  int dev = -1;
+  M3D_HIP(hipGetDevice(&dev));
+  M3D_CHECK_ARG(dev >= 0 && dev < kMaxDevices, "%s: device index %d out of range", who, dev);
+  std::lock_guard<std::mutex> lock(mu);
+  if (ptr[dev] == nullptr) {
+    void* p = nullptr;
+    M3D_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+    M3D_CHECK_ARG(p != nullptr, "%s: no device address for the static scratch array", who);
+    ptr[dev] = static_cast<double*>(p);
+  }
+  *out = ptr[dev];
+  return M3D_OK;
+}
+
 }  // namespace m3d
 
 using namespace m3d;
@@ -161,5 +188,21 @@ extern "C" int m3d_bn_backward_reduce(const float* d_x, const float* d_dy, const
                                       void* stream) {
   M3D_CHECK_ARG(d_dy && d_mean, "m3d_bn_backward_reduce: null pointer");
   return norm_launch("m3d_bn_backward_reduce", d_x, d_dy, d_mean, n, c, d_sum_dy, d_sum_dy_xmu, d_ws, ws_bytes,
+                     static_cast<hipStream_t>(stream));
+}
+
+extern "C" size_t m3d_bn_stats_static_max_bytes(void) { return kStaticScratchBytes; }
+
+extern "C" int m3d_bn_stats_static(const float* d_x, int64_t n, int c, float* d_mean, float* d_var, void* stream) {
+  const char* who = "m3d_bn_stats_static";
+  const size_t need = m3d_bn_workspace_bytes(n, c);
+  if (need > kStaticScratchBytes) {
+    set_error("%s: %lld rows x %d channels need %zu bytes of partial sums, the static scratch holds %zu "
+              "(use m3d_bn_stats with a workspace)", who, (long long)n, c, need, kStaticScratchBytes);
+    return M3D_ENOSPC;
+  }
+  double* ws = nullptr;
+  if (int rc = static_scratch(who, &ws)) return rc;
+  return norm_launch(who, d_x, nullptr, nullptr, n, c, d_mean, d_var, ws, kStaticScratchBytes,
                      static_cast<hipStream_t>(stream));
 }
