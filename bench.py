@@ -3,15 +3,20 @@
 -> CLIP-text logits -> argmax -> per-point labels) on synthetic ScanNet-shaped scenes, inputs resident
 in HBM.  One process per GPU; scenes are sharded across ranks with no data-path collective.
 
-    python bench.py --gpus 1 --steps 10 --warmup 3
+    python bench.py                       # 1 GPU, configs[1] of BASELINE.json (one ~273 k-voxel scene per step)
+    python bench.py --gpus N              # starts N ranks itself (torch.distributed.run) when not already under one
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+    python bench.py --workload cfg3       # configs[2]: 64 scenes of 150-250 k voxels, largest-first over the ranks
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (convolution kernel,
-HIP-event timed on the launch stream) and `cpu_baseline` (the CPU oracle on the host cores).
+Prints ONE JSON line on rank 0 with `roofline` (convolution kernel, HIP-event timed on the launch stream),
+`stages` (voxelizer and kernel maps against the HBM bound), `variants` (the other precisions, same workload),
+`parity` (every precision against a float64 run of the CPU oracle on the full-size scene) and `cpu_baseline`
+(the CPU oracle in f32 on the host cores).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -19,22 +24,26 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import numpy as np
-import torch
-
-PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X dense f32 matrix peak (v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD)
+PEAK_F32_MFMA_TFLOPS = 157.3    # MI355X dense f32 matrix peak (v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD)
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X dense bf16 matrix peak
-# algorithmic-FLOP peak of the convolution kernel per precision: the split paths spend 3 (6) bf16 MFMA
-# products per f32 product
-PEAK = {"f32": PEAK_F32_MFMA_TFLOPS, "bf16x3": PEAK_BF16_MFMA_TFLOPS / 3, "bf16x6": PEAK_BF16_MFMA_TFLOPS / 6}
-DTYPE = {"f32": "f32", "bf16x3": "f32 (products: 3x bf16 MFMA on 2-term splits, f32 accumulate)",
-         "bf16x6": "f32 (products: 6x bf16 MFMA on 3-term splits, f32 accumulate)"}
+PEAK_HBM_GBS = 8000.0
+# peak in algorithmic (f32-product) FLOP/s of the instruction each precision issues: the split paths spend
+# 3 (6) bf16 MFMA products per f32 product, plain bf16 one
+PEAK = {"f32": PEAK_F32_MFMA_TFLOPS, "bf16x6": PEAK_BF16_MFMA_TFLOPS / 6, "bf16x3": PEAK_BF16_MFMA_TFLOPS / 3,
+        "bf16": PEAK_BF16_MFMA_TFLOPS}
+DTYPE = {"f32": "f32 (exact f32 MFMA)",
+         "bf16x6": "f32 (every product: 6 bf16 MFMA products of 3-term splits, f32 accumulate; f32-level accuracy)",
+         "bf16x3": "f32 storage, products from 2-term bf16 splits (3 bf16 MFMA products, f32 accumulate)",
+         "bf16": "bf16 storage, f32 accumulate"}
+HEADLINE = "bf16x6"            # arithmetic not narrower than the reference's fp32 (see `parity` in the output)
 GRID = 0.02
 N_CLASSES = 200
-TARGET_VOXELS = 290_000        # scene-generator target; lands at ~250 k occupied 2 cm voxels
+TARGET_VOXELS = 290_000        # scene-generator target; lands at ~273 k occupied 2 cm voxels
+CFG3_SCENES = 64
 
 
-def build_engine(device, precision="bf16x3"):
+def build_engine(device, precision=HEADLINE):
+    import torch
     from segmentation_amd import spunet
     from segmentation_amd.engine import SpUNetEngine
     from segmentation_amd import scenes
@@ -48,8 +57,30 @@ def build_engine(device, precision="bf16x3"):
     return eng, model, cfg
 
 
-def cpu_baseline(model, cfg, scene, emb):
-    """The reference path restated on the CPU (oracle/), timed on this host's cores on one scene."""
+def cfg3_targets():
+    """Scene-generator targets of the 64-scene job (seeds 0..63): occupied voxels ~ U(150 k, 250 k)."""
+    import numpy as np
+    rng = np.random.default_rng(2024)
+    return [int(v * TARGET_VOXELS / 273_000) for v in rng.uniform(150_000, 250_000, size=CFG3_SCENES)]
+
+
+def my_scene_specs(workload, rank, world, scenes_per_rank, target_voxels):
+    """(seed, target_voxels) of the scenes this rank owns."""
+    from segmentation_amd import sharding
+    if workload == "cfg3":
+        targets = cfg3_targets()
+        # the point count of a generated scene is proportional to its target: largest first over the ranks
+        mine = sharding.assign_scenes(targets, world)[rank]
+        return [(i, targets[i]) for i in mine]
+    # scene i of the job goes to rank i mod world (weak scaling: scenes_per_rank scenes on every GPU)
+    return [(rank + j * world, target_voxels) for j in range(scenes_per_rank)]
+
+
+def cpu_reference(model, cfg, scene, emb):
+    """The reference path restated on the CPU (oracle/): timed in f32 on this host's cores (the baseline), and run
+    once in float64 as the yardstick every GPU precision -- and the f32 CPU run itself -- is measured against."""
+    import numpy as np
+    import torch
     import oracle
     from oracle import spunet as ospunet
     cores = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1)))
@@ -59,15 +90,47 @@ def cpu_baseline(model, cfg, scene, emb):
         P[k[len("backbone."):] if k.startswith("backbone.") else k] = v.detach().float().cpu()
     n = scene["coord"].shape[0]
     off = np.array([0, n], dtype=np.int64)
-    passes = 4  # about 12 s on 16 cores: a bounded sample of the same workload
+    passes = 3  # about 10 s on 16 cores: a bounded sample of the same workload
     t0 = time.perf_counter()
     for _ in range(passes):
-        sp, out = ospunet.spunet_from_points(P, cfg, scene["coord"], scene["feat"], off, GRID)
-        pred = oracle.head_predict(out, sp["v2p_map"], emb)
+        sp, out32 = ospunet.spunet_from_points(P, cfg, scene["coord"], scene["feat"], off, GRID)
+        pred32 = oracle.head_predict(out32, sp["v2p_map"], emb)
     dt = time.perf_counter() - t0
     n0 = sp["voxel_coords"].shape[0]
-    return dict(value=passes * n0 / dt, unit="voxels/s", cores=cores, kind="port",
-                sample=f"{passes} passes over one synthetic scene, N0={n0} voxels / {n} points, {dt:.1f} s wall"), pred
+    P64 = {k: v.double() for k, v in P.items()}
+    _, out64 = ospunet.spunet_from_points(P64, cfg, scene["coord"], scene["feat"], off, GRID, dtype=torch.float64)
+    logits64 = out64 @ emb.double().t()
+    cb = dict(value=passes * n0 / dt, unit="voxels/s", cores=cores, kind="port",
+              sample=f"{passes} f32 passes over one synthetic scene, N0={n0} voxels / {n} points, {dt:.1f} s wall")
+    return cb, dict(sp=sp, feat64=out64, logits64=logits64, feat32=out32, pred32=pred32)
+
+
+def feature_errors(f, ref64):
+    """Per-voxel relative error of features f [N, D] against the float64 reference: max and mean over voxels of
+    ||f - ref||_2 / ||ref||_2."""
+    import torch
+    d = (f.double() - ref64).norm(dim=1) / ref64.norm(dim=1).clamp_min(1e-30)
+    return float(d.max()), float(d.mean())
+
+
+def label_agreement(pred_points, ref, top2_margin=None):
+    import torch
+    v2p = torch.as_tensor(ref["sp"]["v2p_map"], dtype=torch.int64)
+    ref_pred = ref["logits64"].max(1)[1][v2p]
+    return float((pred_points.cpu() == ref_pred).double().mean())
+
+
+def launch_ranks(args, argv):
+    """`bench.py --gpus N` outside a distributed launcher: start N ranks as a child job (nothing in this process
+    has touched a GPU yet) and pass its output through."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    return subprocess.call(cmd)
 
 
 def main():
@@ -75,18 +138,50 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3"],
+                    help="cfg2: one ScanNet-scale scene per GPU and step (weak scaling); cfg3: 64 scenes of "
+                         "150-250 k voxels shared out largest-first (strong scaling)")
     ap.add_argument("--target-voxels", type=int, default=TARGET_VOXELS)
     ap.add_argument("--scenes-per-rank", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--precision", default="bf16x3", choices=["f32", "bf16x6", "bf16x3"],
-                    help="how f32 products are formed: exact f32 MFMA, or bf16 MFMA on 3-/2-term splits")
+    ap.add_argument("--precision", default=HEADLINE, choices=["f32", "bf16x6", "bf16x3", "bf16"],
+                    help="how products are formed: exact f32 MFMA, bf16 MFMA on 3-/2-term splits of f32, plain bf16")
     ap.add_argument("--fold-head", action="store_true", help="fold `final` into the text matrix (not the headline)")
-    ap.add_argument("--no-variants", action="store_true", help="skip the secondary (folded-head) measurement")
+    ap.add_argument("--no-variants", action="store_true", help="skip the measurements of the other precisions")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="rehearse the launch, sharding and reduction on the CPU (gloo), no kernels")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        raise SystemExit(launch_ranks(args, sys.argv[1:]))
+
+    import numpy as np
+    import torch
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
+    if world != args.gpus and rank == 0:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; reporting n_gpus={world}", file=sys.stderr)
+    from segmentation_amd import sharding
+    specs = my_scene_specs(args.workload, rank, world, args.scenes_per_rank, args.target_voxels)
+    scaling = "strong" if args.workload == "cfg3" else "weak"
+
+    if args.dry_run:
+        dist = None
+        if world > 1:
+            import torch.distributed as dist
+            dist.init_process_group("gloo")
+        units = float(sum(t for _, t in specs))
+        elapsed, total = sharding.reduce_job(1.0 + 0.25 * rank, units, dist, None)
+        if rank == 0:
+            print(json.dumps(dict(metric="voxels/sec SpUNet fwd", dry_run=True, n_gpus=world, value=total / elapsed,
+                                  unit="voxels/s", scaling=scaling, scenes_rank0=[s for s, _ in specs],
+                                  config=dict(workload=args.workload))), flush=True)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an AMD GPU")
     torch.cuda.set_device(local)
@@ -100,18 +195,17 @@ def main():
     from segmentation_amd import ops, scenes
     eng, model, cfg = build_engine(device, args.precision)
 
-    # scene i of the job goes to rank i mod world (weak scaling: scenes_per_rank scenes on every GPU)
     my = []
-    for j in range(args.scenes_per_rank):
-        sc = scenes.make_scene(seed=rank + j * world, target_voxels=args.target_voxels)
+    for seed, target in specs:
+        sc = scenes.make_scene(seed=seed, target_voxels=target)
         n = sc["coord"].shape[0]
         my.append(dict(coord=torch.from_numpy(sc["coord"]).to(device), feat=torch.from_numpy(sc["feat"]).to(device),
-                       offset=np.array([0, n], dtype=np.int64), host=sc))
+                       offset=np.array([0, n], dtype=np.int64), host=sc if len(my) == 0 else None))
 
-    def step():
+    def step(e=eng, fold=args.fold_head):
         nv = 0
         for sc in my:
-            out = eng.predict(sc["coord"], sc["feat"], sc["offset"], GRID, fold_head=args.fold_head)
+            out = e.predict(sc["coord"], sc["feat"], sc["offset"], GRID, fold_head=fold)
             nv += out["n_voxels"]
         return nv
 
@@ -121,41 +215,48 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    with torch.no_grad():
-        for _ in range(args.warmup):
-            step()
+    def timed(fn, steps, warmup):
+        for _ in range(warmup):
+            fn()
         barrier()
         t0 = time.perf_counter()
-        nvox = 0
-        for _ in range(args.steps):
-            nvox += step()
+        nv = 0
+        for _ in range(steps):
+            nv += fn()
         barrier()
-        elapsed = time.perf_counter() - t0
+        return time.perf_counter() - t0, nv
 
-        # secondary measurement (not the headline): `final` (96 -> 768) folded into the text matrix on the host,
-        # logits = x96 . (E Wf)^T + E b -- the same labels without materialising the 768-d features
-        folded_ms = None
-        if not args.fold_head and not args.no_variants:
-            for sc in my:
-                eng.predict(sc["coord"], sc["feat"], sc["offset"], GRID, fold_head=True)
-            barrier()
-            tf = time.perf_counter()
-            for _ in range(args.steps):
-                for sc in my:
-                    eng.predict(sc["coord"], sc["feat"], sc["offset"], GRID, fold_head=True)
-            barrier()
-            folded_ms = (time.perf_counter() - tf) / args.steps * 1e3
+    with torch.no_grad():
+        elapsed, nvox = timed(step, args.steps, args.warmup)
 
-        # convolution-kernel roofline: HIP events around every launch of one more step (rank 0's stream)
+        # convolution-kernel roofline: HIP events around every launch of a few more steps (this rank's stream)
+        psteps = min(args.steps, 5)
         ops.PROFILE = []
         step()                      # counts pairs per schedule (host syncs) -- not used for timing
         ops.PROFILE = []
-        for _ in range(min(args.steps, 5)):
+        for _ in range(psteps):
             step()
         torch.cuda.synchronize()
         prof, ops.PROFILE = ops.PROFILE, None
+        stage_stats = stage_rates(eng, my[0], ops) if rank == 0 else None
 
-    from segmentation_amd import sharding
+        # the other precisions on the same workload (secondary numbers; single rank only)
+        variants = {}
+        engines = {args.precision: eng}
+        if world == 1 and not args.no_variants and not args.fold_head:
+            for p in ("f32", "bf16x6", "bf16x3", "bf16"):
+                if p == args.precision or p not in ops.PRECISION:
+                    continue
+                e2, _, _ = build_engine(device, p)
+                engines[p] = e2
+                dt, nv = timed(lambda: step(e2, False), max(args.steps // 2, 3), 2)
+                steps_v = max(args.steps // 2, 3)
+                variants[p] = dict(ms_per_step=dt / steps_v * 1e3, voxels_per_s=nv / dt, dtype=DTYPE[p])
+            dt, nv = timed(lambda: step(eng, True), max(args.steps // 2, 3), 2)
+            variants["fold_head"] = dict(ms_per_step=dt / max(args.steps // 2, 3) * 1e3, voxels_per_s=nv / dt,
+                                         note=f"{args.precision} with final 96->768 folded into the text matrix: same "
+                                              "labels, 768-d features never formed; not the headline")
+
     elapsed, nvox_all = sharding.reduce_job(elapsed, float(nvox), dist, device)
 
     if rank == 0:
@@ -166,43 +267,89 @@ def main():
         achieved = flops / secs / 1e12 if secs > 0 else 0.0
         # HBM bytes per launch of the same kernels from the committed rocprofv3 --pmc passes (separate runs)
         traffic = None
-        pmc = os.path.join(ROOT, "profiles", f"r01_{args.precision}_conv_pmc.json")
+        pmc = os.path.join(ROOT, "profiles", f"r02_{args.precision}_conv_pmc.json")
         if os.path.exists(pmc):
             traffic = json.load(open(pmc))["all_conv_igemm"]["traffic_bytes_per_launch"]
         peak = PEAK[args.precision]
         kname = "m3d::conv_igemm_f32_kernel<*>" if args.precision == "f32" else "m3d::conv_igemm_dma_kernel<*>"
-        roofline = dict(bound="mfma", achieved=achieved, peak=peak, unit="TFLOP/s",
-                        frac=achieved / peak, traffic=traffic, frac_of_f32_matrix_peak=achieved / PEAK_F32_MFMA_TFLOPS,
-                        kernel=kname + " (all tile shapes)", launches_per_step=nl // min(args.steps, 5),
+        roofline = dict(bound="mfma", achieved=achieved, peak=peak, unit="TFLOP/s", frac=achieved / peak, traffic=traffic,
+                        kernel=kname + " (all tile shapes)", launches_per_step=nl // psteps,
                         flop_per_launch=flops / nl, avg_launch_us=secs / nl * 1e6,
-                        conv_share_of_step=secs / min(args.steps, 5) / (elapsed / args.steps))
-        cb = None
-        if world == 1 and not args.no_cpu_baseline:
-            from segmentation_amd import scenes as _s
-            emb = torch.from_numpy(_s.text_embeddings(N_CLASSES, cfg["out_channels"], seed=1))
-            cb, ref_pred = cpu_baseline(model, cfg, my[0]["host"], emb)
+                        conv_share_of_step=secs / psteps / (elapsed / args.steps),
+                        peak_note="dense matrix peak of the instruction issued, in f32-product FLOP/s "
+                                  "(bf16 MFMA peak / products per f32 product)")
+        cb = parity = None
+        if world == 1 and not args.no_cpu_baseline and my[0]["host"] is not None:
+            emb = torch.from_numpy(scenes.text_embeddings(N_CLASSES, cfg["out_channels"], seed=1))
+            cb, ref = cpu_reference(model, cfg, my[0]["host"], emb)
+            e32 = feature_errors(ref["feat32"], ref["feat64"])
+            v2p = torch.as_tensor(ref["sp"]["v2p_map"], dtype=torch.int64)
+            parity = dict(reference="CPU oracle in float64 on the same scene; feature_rel_err = per-voxel "
+                                    "||f - ref||_2 / ||ref||_2 (max and mean over voxels); labels per point",
+                          cpu_oracle_f32=dict(feature_rel_err_max=e32[0], feature_rel_err_mean=e32[1],
+                                              label_agreement=float((ref["pred32"] == ref["logits64"].max(1)[1][v2p])
+                                                                    .double().mean())))
+            sc0 = my[0]
             with torch.no_grad():
-                out = eng.predict(my[0]["coord"], my[0]["feat"], my[0]["offset"], GRID, fold_head=args.fold_head)
-            cb["label_agreement_vs_gpu"] = float((out["pred"].cpu() == ref_pred).float().mean())
+                for p, e in engines.items():
+                    f, vox = e.forward_features(sc0["coord"], sc0["feat"], sc0["offset"], GRID)
+                    assert np.array_equal(vox["voxel_coords"].cpu().numpy(), ref["sp"]["voxel_coords"])
+                    assert np.array_equal(vox["v2p_map"].cpu().numpy(), ref["sp"]["v2p_map"])
+                    mx, mean = feature_errors(f.cpu(), ref["feat64"])
+                    del f
+                    out = e.predict(sc0["coord"], sc0["feat"], sc0["offset"], GRID, fold_head=False)
+                    parity[p] = dict(feature_rel_err_max=mx, feature_rel_err_mean=mean,
+                                     label_agreement=label_agreement(out["pred"], ref),
+                                     voxel_order_and_maps="bit-exact")
+            cb["label_agreement_vs_gpu"] = parity[args.precision]["label_agreement"]
         st = eng.last_stats
+        wl = ("configs[1]: synthetic ScanNet-scale scene @2 cm, spunet34c+ppt forward + 768-d CLIP-text argmax "
+              "(C=200), voxelize+kernel maps included") if args.workload == "cfg2" else \
+             ("configs[2]: 64 synthetic scenes of 150-250 k voxels @2 cm, shared out largest-first over the ranks, "
+              "spunet34c+ppt forward + 768-d CLIP-text argmax (C=200), voxelize+kernel maps included")
         line = dict(metric="voxels/sec SpUNet fwd", value=nvox_all / elapsed, unit="voxels/s", n_gpus=world,
                     steps=args.steps, warmup=args.warmup, ms_per_step=elapsed / args.steps * 1e3,
-                    higher_is_better=True, scaling="weak", vs_baseline=None, dtype=DTYPE[args.precision], data="synthetic",
-                    config=dict(workload="configs[1]: synthetic ScanNet-scale scene @2 cm, spunet34c+ppt forward "
-                                         "fp32 + 768-d CLIP-text argmax (C=200), voxelize+kernel maps included",
-                                scenes_per_gpu=args.scenes_per_rank, voxels_per_scene=st.get("n_voxels", [0])[0],
+                    higher_is_better=True, scaling=scaling, vs_baseline=None, dtype=DTYPE[args.precision],
+                    data="synthetic",
+                    config=dict(workload=wl, scenes_rank0=len(my), voxels_per_scene=st.get("n_voxels", [0])[0],
                                 points_per_scene=st.get("n_points", 0), level_voxels=st.get("n_voxels"),
                                 parallelism=f"scene-sharded x{world}, no collectives", fold_head=args.fold_head,
                                 precision=args.precision),
-                    roofline=roofline, cpu_baseline=cb,
-                    variants=None if folded_ms is None else dict(
-                        fold_head=dict(ms_per_step=folded_ms, voxels_per_s_this_rank=nvox / args.steps / (folded_ms * 1e-3),
-                                       note="final 96->768 folded into the text matrix; labels identical in tests; "
-                                            "not the headline because the 768-d features are never formed")))
+                    roofline=roofline, stages=stage_stats, cpu_baseline=cb, parity=parity, variants=variants or None)
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def stage_rates(eng, sc, ops):
+    """Voxelizer and kernel-map phases of one scene against the HBM bound: HIP events on the launch stream around
+    each phase (median of 5), algorithmic bytes from the sizes of what each phase must read and write."""
+    import numpy as np
+    import torch
+    ev = lambda: torch.cuda.Event(enable_timing=True)
+    tv, tm = [], []
+    for _ in range(5):
+        e0, e1, e2 = ev(), ev(), ev()
+        e0.record()
+        vox = ops.voxelize(sc["coord"], sc["feat"], sc["offset"], GRID, pad=128)
+        e1.record()
+        levels = eng.build_levels(vox["voxel_coords"], vox["spatial_shape"], vox["batch_size"])
+        e2.record()
+        torch.cuda.synchronize()
+        tv.append(e0.elapsed_time(e1) * 1e-3)
+        tm.append(e1.elapsed_time(e2) * 1e-3)
+    npts, c = sc["feat"].shape
+    ns = [lv.n for lv in levels]
+    # voxelizer: points in (coord, feat), v2p_map out, voxels out (coords, feats)
+    vbytes = npts * (12 + 4 * c + 8) + ns[0] * (16 + 4 * c)
+    # kernel maps per level: coordinates in, 27-column submanifold map out, both 8-column strided maps out
+    mbytes = sum(n * 16 + 27 * n * 4 for n in ns) + sum(8 * 4 * (ns[l] + ns[l + 1]) for l in range(len(ns) - 1))
+    out = {}
+    for name, t, b in (("voxelize", float(np.median(tv)), vbytes), ("kernel_maps_and_schedules", float(np.median(tm)), mbytes)):
+        out[name] = dict(ms=t * 1e3, algorithmic_bytes=b, achieved_gbs=b / t / 1e9, peak_gbs=PEAK_HBM_GBS,
+                         frac=b / t / 1e9 / PEAK_HBM_GBS, bound="hbm")
+    return out
 
 
 if __name__ == "__main__":

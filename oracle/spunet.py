@@ -183,9 +183,10 @@ def build_rulebooks(voxel_coords, spatial_shape, num_stages=4):
 
 
 def spunet_forward(P, cfg, voxel_feats, voxel_coords, spatial_shape, condition="ScanNet",
-                   levels=None, return_intermediates=False):
+                   levels=None, return_intermediates=False, dtype=torch.float32):
     """SpUNetBase.forward after sparsify (v1m3:384-407) with PPT's context (ppt/model.py:15-22).
-    Returns per-voxel features [N0, out_channels] (and optionally a dict of layer outputs)."""
+    Returns per-voxel features [N0, out_channels] (and optionally a dict of layer outputs).
+    dtype=torch.float64 (with float64 parameters) gives the yardstick that f32 runs are measured against."""
     ch, layers = cfg["channels"], cfg["layers"]
     ns = len(layers) // 2
     ci = list(cfg["conditions"]).index(condition)
@@ -193,7 +194,7 @@ def spunet_forward(P, cfg, voxel_feats, voxel_coords, spatial_shape, condition="
     if levels is None:
         levels = build_rulebooks(voxel_coords, spatial_shape, ns)
     inter = {}
-    x = torch.as_tensor(voxel_feats, dtype=torch.float32)
+    x = torch.as_tensor(voxel_feats).to(dtype)
     x = subm_conv(x, P["conv_input.conv.weight"], levels[0]["subm"])
     x = torch.relu(pdnorm(P, "conv_input.bn", x, ci, context))
     inter["conv_input"] = x

@@ -90,3 +90,27 @@ def test_gradient_allreduce_two_ranks_gloo():
     assert nb0 == nb1 and nb0 >= 2
     for a, b, m0, m1 in zip(local0, local1, avg0, avg1):
         assert torch.allclose(m0, (a + b) / 2) and torch.equal(m0, m1)
+
+
+def test_bench_starts_its_own_ranks_dry_run():
+    """`python bench.py --gpus 2` outside a launcher starts two ranks itself (before anything touches a GPU) and
+    relays rank 0's JSON line; --dry-run rehearses sharding and the job reduction over gloo without kernels."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    for workload, scaling in (("cfg2", "weak"), ("cfg3", "strong")):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run", "--workload",
+                            workload], capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1
+        d = json.loads(lines[0])
+        assert d["n_gpus"] == 2 and d["dry_run"] and d["scaling"] == scaling
+        if workload == "cfg3":
+            import bench
+            targets = bench.cfg3_targets()
+            assert len(targets) == 64 and abs(d["value"] * 1.25 - sum(targets)) < 1e-6 * sum(targets)
+            parts = sharding.assign_scenes(targets, 2)
+            assert d["scenes_rank0"] == parts[0] and len(parts[0]) + len(parts[1]) == 64
