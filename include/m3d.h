@@ -35,6 +35,7 @@ extern "C" {
 #define M3D_PREC_F32 0     /* exact f32 products on v_mfma_f32_32x32x2_f32 */
 #define M3D_PREC_BF16X3 1  /* f32 operands split in 2 bf16 terms, 3 bf16 MFMA products (~2^-17 per product) */
 #define M3D_PREC_BF16X6 2  /* f32 operands split in 3 bf16 terms, 6 bf16 MFMA products (~2^-24 per product) */
+#define M3D_PREC_BF16 3    /* operands rounded to bf16, one bf16 MFMA product, f32 accumulation (~2^-8 per product) */
 
 #define M3D_HASH_FNV 0
 #define M3D_HASH_RAVEL 1
@@ -201,7 +202,7 @@ int m3d_schedule_tile_order(const uint32_t* d_tile_mask, int64_t npad, int32_t* 
  *   d_in0 [*,c0], d_in1 [*,c1] (d_in1 may be NULL, c1 = 0): the two K-slabs of a concatenated
  *        input (spconv_unet_v1m3_pdnorm.py:404) read without materialising the concat
  *   d_weight: the reference's [Cout,k0,k1,k2,Cin] f32 weight converted by m3d_conv_pack_weight for
- *        the same `precision` ([k,cout,cin] f32, or pre-split bf16 terms)
+ *        the same `precision` ([k,cout,cin] f32, or pre-split bf16 terms [k,cout,cin/G,terms,G])
  *   d_nbr/d_out_row/d_tile_mask: from m3d_build_schedule; all three NULL = dense 1x1 (k = 1)
  *   d_tile_order: NULL or m3d_schedule_tile_order's output for this schedule (launch order of 128-row tiles)
  *   d_scale/d_shift [cout] may be NULL (1 / 0); d_residual [n_out_rows,cout] may be NULL
@@ -218,9 +219,11 @@ int m3d_conv_fwd_f32(const float* d_in0, int c0, const float* d_in1, int c1,
                      void* stream);
 
 /* Same convolution with the activations in the engine-internal split format "sf32":
- *   [rows + 1][C/32][terms][32] bf16, term t = bf16 rounding of what terms < t left over, row `rows`
- *   all zero (missing neighbours gather it).  Inputs are moved to LDS by per-lane-addressed LDS-DMA
- *   (global_load_lds_dwordx4); products as in M3D_PREC_BF16X3 (terms = 2) / M3D_PREC_BF16X6 (terms = 3).
+ *   [rows + 1][C/G][terms][G] bf16 with G = 16 channels per group for terms = 3 and 32 otherwise (terms = 1 is plain
+ *   row-major bf16), term t = bf16 rounding of what terms < t left over, row `rows` all zero (missing neighbours
+ *   gather it).  Inputs are moved to LDS by per-lane-addressed LDS-DMA (global_load_lds_dwordx4); products as in
+ *   M3D_PREC_BF16 (terms = 1) / M3D_PREC_BF16X3 (terms = 2) / M3D_PREC_BF16X6 (terms = 3; the leading products and
+ *   the small ones are accumulated separately and added once at the end).
  *   d_tile_order: NULL or m3d_schedule_tile_order's output for this schedule.
  *   d_weight: m3d_conv_pack_weight output for that precision.  Outputs: d_out (f32, may be NULL) and/or
  *   d_out_split (sf32 with cout/32 groups, may be NULL); m3d_conv_fwd_f32 can write d_out_split too

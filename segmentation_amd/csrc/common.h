@@ -31,6 +31,29 @@ void set_error(const char* fmt, ...);
 
 #define M3D_LAUNCH_CHECK() M3D_HIP(hipGetLastError())
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-device property of a kernel: one of these per kernel
+// instantiation (a function-local static) remembers, per device, the largest size already granted.  Racing first
+// calls from two threads both set the attribute, which is harmless.
+struct LdsGrant {
+  size_t have[64] = {};
+  int ensure(const void* fn, size_t lds) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) {
+      set_error("hipGetDevice failed or device index out of range");
+      return M3D_EHIP;
+    }
+    if (lds > have[dev]) {
+      hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) {
+        set_error("hipFuncSetAttribute(%zu bytes of LDS) -> %s", lds, hipGetErrorString(e));
+        return M3D_EHIP;
+      }
+      have[dev] = lds;
+    }
+    return M3D_OK;
+  }
+};
+
 static inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 

@@ -176,8 +176,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_f32_kernel(ConvArgs a
 //   T = 3: + x1*w1 + x0*w2 + x2*w0                     (relative error ~2^-24, i.e. f32 level)
 // bf16 products are exact in f32, so only the dropped cross terms and the accumulation round.
 // The bf16 pipe is 16x the f32 matrix rate per k, so 3 (6) products cost 3/16 (6/16) of the exact
-// kernel's matrix time.  Weights arrive pre-split ([k][Cout][Cin/32][T][32] bf16); activations are
-// gathered as f32 and split while they are committed to LDS.
+// kernel's matrix time.  T = 1 is plain bf16: one term, one product.  Weights arrive pre-split
+// ([k][Cout][Cin/G][T][G] bf16, G = 16 for T = 3 and 32 otherwise); activations are gathered as f32 and
+// split while they are committed to LDS.
 constexpr int kRowB = 80;  // LDS bytes per row and term: 32 bf16 + 16 B pad (conflict-free b128 reads)
 
 template <int WM, int WN, int NT, int T>
@@ -246,11 +247,14 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_split_kernel(ConvArgs
 #pragma unroll
     for (int v = 0; v < W_V; ++v) {
       const int e = tid + v * NTHR;
-      const int j = e / (T * 4), p = e % (T * 4);
+      const int j = e / (T * 4), p = e % (T * 4);  // p = 4 * term + 8-channel piece of the 32-channel slab
       uint4 x = make_uint4(0, 0, 0, 0);
-      if (e < W_E)
-        x = *reinterpret_cast<const uint4*>(
-            wsplit + (((int64_t)k * a.cout + col_base + j) * nchunk + cc) * (T * 64) + p * 16);
+      if (e < W_E) {
+        const int64_t row = (int64_t)k * a.cout + col_base + j;
+        const char* src = T == 3 ? wsplit + (row * (2 * nchunk) + 2 * cc + ((p >> 1) & 1)) * 96 + (p >> 2) * 32 + (p & 1) * 16
+                                 : wsplit + (row * nchunk + cc) * (T * 64) + p * 16;
+        x = *reinterpret_cast<const uint4*>(src);
+      }
       rw[v] = x;
     }
   };
@@ -322,13 +326,15 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_split_kernel(ConvArgs
 #pragma unroll
             for (int t = 0; t < T; ++t)
               bf[t] = *reinterpret_cast<const bf16x8*>(Wb + t * W_PLANE + nt * 32 * kRowB + ks * 32);
-            if (T == 3) {
+            if constexpr (T == 3) {
               acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[T - 1], acc[nt], 0, 0, 0);
               acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[T - 1], bf[0], acc[nt], 0, 0, 0);
               acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[1], acc[nt], 0, 0, 0);
             }
-            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[1], acc[nt], 0, 0, 0);
-            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[0], acc[nt], 0, 0, 0);
+            if constexpr (T >= 2) {
+              acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[T - 1 > 0 ? 1 : 0], acc[nt], 0, 0, 0);
+              acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[T - 1 > 0 ? 1 : 0], bf[0], acc[nt], 0, 0, 0);
+            }
             acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[0], acc[nt], 0, 0, 0);
           }
         }
@@ -346,24 +352,50 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_split_kernel(ConvArgs
 
 // ------------------------------------------------------------------------------------------
 // LDS-DMA variant of the split-bf16 kernel.  Activations arrive already split ("sf32":
-// [rows + 1][C/32][T][32] bf16, the extra row all zero), so a stage is a pure byte move: every lane
+// [rows + 1][C/G][T][G] bf16, the extra row all zero), so a stage is a pure byte move: every lane
 // issues global_load_lds_dwordx4 with its own source address (row gather) and the hardware writes the
 // 64 lanes' 16-B pieces to consecutive LDS slots -- no staging registers, no VALU, no ds_write.
-// LDS image: one row per gathered row, SLOTS 16-B slots (8 for T = 2, 16 for T = 3, 12 used); slot
-// p' of row r holds piece p' ^ swz(r), so the fragment reads (16 lanes, distinct rows, same piece)
+// The reduction walks units = (active kernel offset, group of G channels).  LDS image: one row per gathered
+// row and stage: T = 2 one unit of 32 channels (terms 0 and 1, 128 bytes), T = 3 one unit of 16 channels
+// (three terms, 96 bytes), T = 1 two consecutive units of 32 channels (128 bytes) -- every stage then
+// carries 12-18 matrix instructions per wave for 21-28 KB of LDS, at two workgroups per CU.
+// Slot p' of row r holds piece p' ^ swz(r), so the fragment reads (16 lanes, distinct rows, same piece)
 // hit distinct banks although the image is lane-linear.  Missing neighbours read the zero row.
-// Pipeline: two LDS buffers; the DMA of stage s+2 is issued right after stage s has been consumed and
-// lands during stage s+1 (counted s_waitcnt vmcnt, raw s_barrier); the kernel map of the tile is
+// Pipeline: two LDS buffers; the DMA of stage s+1 is issued right after the barrier that publishes stage s
+// and lands while stage s is multiplied (s_waitcnt vmcnt, raw s_barrier); the kernel map of the tile is
 // staged in LDS once so that no ordinary global load sits between DMAs.
+// T = 3 keeps two accumulator sets: the leading products a0*w0 and everything else (2^-8 and below).  The
+// small products then round against their own small running sum instead of the large one, and the result is
+// more accurate than a single f32 accumulation chain over the same terms.
+
+#ifdef M3D_STAMP
+// Diagnostic build only (make stamp): where a stage of the LDS-DMA kernel spends its cycles.  Sums over all waves of
+// [0] cycles from loop top to past the barrier, [1] issuing the next stage's DMA, [2] matrix work, [3] stages,
+// [4] prologue, [5] epilogue.  Never compiled into the shipped library.
+__device__ unsigned long long m3d_stamp_sums[8];
+#define M3D_T(var) unsigned long long var; __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); __builtin_amdgcn_sched_barrier(0)
+#endif
+
+struct UnitIt {  // position in the unit sequence of a tile: kernel offset k (lowest set bit of rem), channel group cc
+  uint32_t rem;
+  int k, cc;
+};
 
 template <int WM, int WN, int NT, int T, int NBUF>
 __device__ __forceinline__ void conv_igemm_dma_body(const ConvArgs& a) {
   using G = DmaGeom<T>;
   constexpr int BM = 32 * WM, BN = 32 * NT * WN, NTHR = 64 * WM * WN;
   constexpr int A_BYTES = BM * G::ROWB, W_BYTES = BN * G::ROWB, BUF = A_BYTES + W_BYTES;
-  constexpr int A_V = BM * G::SLOTS / NTHR, W_V = BN * G::SLOTS / NTHR;
-  constexpr int GRPB = G::PIECES * 16;  // bytes of one (row, 32-channel group) in HBM
-  static_assert(BM * G::SLOTS % NTHR == 0 && BN * G::SLOTS % NTHR == 0, "every wave must issue the same DMA count");
+  // DMA instructions per thread and stage; where the slot count does not divide by the thread count the last
+  // instruction is issued by the leading waves only (and its last wave by its leading lanes)
+  constexpr int A_V = (BM * G::SLOTS + NTHR - 1) / NTHR, W_V = (BN * G::SLOTS + NTHR - 1) / NTHR;
+  constexpr int GRPB = G::PIECES * 16;  // bytes of one (row, unit) in HBM
+  constexpr int UPS = G::UPS;
+  static_assert(A_BYTES % 256 == 0 && BUF % 256 == 0, "every image starts on a bank line");
+  // slot lists that divide evenly by the thread count and have no unused slot need no lane mask
+  constexpr bool A_EXACT = BM * G::SLOTS % NTHR == 0, W_EXACT = BN * G::SLOTS % NTHR == 0;
+  constexpr bool NO_DEAD = G::PIECES * UPS == G::SLOTS;
+  static_assert(NBUF >= 2 && NBUF <= 4, "ring depth");
   extern __shared__ __align__(16) char ldsb[];
   constexpr int RING = NBUF * BUF > BM * BN * 4 ? NBUF * BUF : BM * BN * 4;  // the output tile is staged here too
   int* idx_s = reinterpret_cast<int*>(ldsb + RING);  // [kvol][BM]
@@ -374,10 +406,10 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvArgs& a) {
   const int wm = wave / WN, wn = wave % WN;
   const int64_t tile_base = (BM == 128 && a.tile_order ? (int64_t)a.tile_order[blockIdx.x] : xcd_tile(blockIdx.x, gridDim.x)) * BM;
   const int col_base = blockIdx.y * BN;
-  const int nchunk = (a.c0 + a.c1) / kBK;
-  const int g0 = a.c0 / kBK;
+  const int nchunk = (a.c0 + a.c1) / G::G;
+  const int g0 = a.c0 / G::G;
   const char* wsplit = reinterpret_cast<const char*>(a.weight);
-  const uint32_t rowb0 = (uint32_t)g0 * GRPB, rowb1 = (uint32_t)(a.c1 / kBK) * GRPB;
+  const uint32_t rowb0 = (uint32_t)g0 * GRPB, rowb1 = (uint32_t)(a.c1 / G::G) * GRPB;
 
   uint32_t bmask, wmask;
   conv_masks<WM>(a, tile_base, wm, bmask, wmask);
@@ -393,152 +425,282 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvArgs& a) {
   }
   __syncthreads();
 
-  floatx16 acc[NT];
+  constexpr int NACC = T == 3 ? 2 : 1;
+  floatx16 acc[NACC][NT];
 #pragma unroll
-  for (int i = 0; i < NT; ++i)
+  for (int c = 0; c < NACC; ++c)
 #pragma unroll
-    for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) acc[c][i][j] = 0.f;
 
-  const int nstage = __popc(bmask) * nchunk;
+  const int nunit = __popc(bmask) * nchunk;
+  const int nstage = (nunit + UPS - 1) / UPS;
 
   // Loop-invariant per-thread addressing.  Slot e = v * NTHR + tid of a buffer is (row e / SLOTS, physical
-  // slot e % SLOTS) and carries logical piece p = slot ^ swz(row).
+  // slot e % SLOTS) and carries logical piece p = slot ^ swz(row); with two units per stage (T = 1) pieces
+  // 0-3 belong to the stage's first unit and 4-7 to its second.
   int a_r[A_V];
   uint32_t a_p[A_V];
-  bool a_on[A_V];
+  bool a_on[A_V], a_u[A_V];
 #pragma unroll
   for (int v = 0; v < A_V; ++v) {
     const int e = v * NTHR + tid;
     a_r[v] = e / G::SLOTS;
     const int p = (e % G::SLOTS) ^ G::swz(a_r[v]);
-    a_p[v] = (uint32_t)p * 16u;
-    a_on[v] = T == 2 || p < G::PIECES;
+    a_u[v] = UPS == 2 && p >= G::PIECES;
+    a_p[v] = (uint32_t)(UPS == 2 ? p & 3 : p) * 16u;
+    a_on[v] = e < BM * G::SLOTS && p < G::PIECES * UPS;
   }
   uint32_t w_o[W_V];
-  bool w_on[W_V];
+  bool w_on[W_V], w_u[W_V];
 #pragma unroll
   for (int v = 0; v < W_V; ++v) {
     const int e = v * NTHR + tid;
     const int j = e / G::SLOTS;
     const int p = (e % G::SLOTS) ^ G::swz(j);
-    w_o[v] = (uint32_t)((col_base + j) * nchunk) * GRPB + (uint32_t)p * 16u;
-    w_on[v] = T == 2 || p < G::PIECES;
+    w_u[v] = UPS == 2 && p >= G::PIECES;
+    w_o[v] = (uint32_t)((col_base + j) * nchunk) * GRPB + (uint32_t)(UPS == 2 ? p & 3 : p) * 16u;
+    w_on[v] = e < BN * G::SLOTS && p < G::PIECES * UPS;
   }
   const uint32_t wk_stride = (uint32_t)(a.cout * nchunk) * GRPB;  // bytes of one kernel offset's weights
-  // Issue iterator: (ik, icc) is the next stage to request, a_id the gathered rows of kernel offset ik.
+
   // (Lambdas here are only ever called from the kernel body itself, never from one another.)
-  int a_id[A_V];
-  uint32_t rem = bmask;
-  int ik = bmask ? __builtin_ctz(bmask) : 0, icc = 0, issued = 0;
-#pragma unroll
-  for (int v = 0; v < A_V; ++v) a_id[v] = idx_s[ik * BM + a_r[v]];
-  auto issue_next = [&](int bi) {
-    char* buf = ldsb + bi * BUF;
-    const bool first = icc < g0;
-    const char* src = (first ? a.s0 : a.s1) + (first ? icc : icc - g0) * GRPB;
-    const uint32_t rowb = first ? rowb0 : rowb1;
-    const int zero = (int)(first ? a.zero0 : a.zero1);
-#pragma unroll
-    for (int v = 0; v < A_V; ++v) {
-      const uint32_t row = (uint32_t)(a_id[v] < 0 ? zero : a_id[v]);
-      const char* g = src + ((uint64_t)row * rowb + a_p[v]);
-      if (a_on[v])
-        __builtin_amdgcn_global_load_lds(g, (lds_ptr_t)(buf + (v * NTHR + wave * 64) * 16), 16, 0, 0);
-    }
-    const char* wsrc = wsplit + ((uint64_t)ik * wk_stride + (uint32_t)icc * GRPB);
-#pragma unroll
-    for (int v = 0; v < W_V; ++v)
-      if (w_on[v])
-        __builtin_amdgcn_global_load_lds(wsrc + w_o[v], (lds_ptr_t)(buf + A_BYTES + (v * NTHR + wave * 64) * 16), 16, 0, 0);
-    ++issued;
-    if (++icc == nchunk) {
-      icc = 0;
-      rem &= rem - 1;
-      if (rem) {
-        ik = __builtin_ctz(rem);
-#pragma unroll
-        for (int v = 0; v < A_V; ++v) a_id[v] = idx_s[ik * BM + a_r[v]];
-      }
+  auto step = [&](UnitIt& u) {
+    if (++u.cc == nchunk) {
+      u.cc = 0;
+      u.rem &= u.rem - 1;
+      if (u.rem) u.k = __builtin_ctz(u.rem);
     }
   };
-
-  // fragment addresses (loop invariant): row of A / W this lane reads, with the swizzle applied per piece
-  const int r32 = lane & 31, h = lane >> 5;
-  const int arow = wm * 32 + r32;
-  uint32_t a_off[2][T], w_off[NT][2][T];
+  // Issue iterator: `it` is the next unit to request, a_id the gathered rows of the units of the next stage.
+  UnitIt it{bmask, bmask ? __builtin_ctz(bmask) : 0, 0};
+  int issued = 0;  // units requested so far
+  int a_id[A_V];
+  auto load_ids = [&]() {
+    UnitIt n1 = it;
+    if (UPS == 2) step(n1);
 #pragma unroll
-  for (int ks = 0; ks < 2; ++ks)
+    for (int v = 0; v < A_V; ++v) a_id[v] = idx_s[(a_u[v] ? n1.k : it.k) * BM + a_r[v]];
+  };
+  load_ids();
+  // DMA instructions this wave issues per stage (the same for every stage): the counted waits below depend on it
+  int gw = 0;
 #pragma unroll
-    for (int t = 0; t < T; ++t) {
-      a_off[ks][t] = arow * G::ROWB + (((t * 4 + ks * 2 + h) ^ G::swz(arow)) * 16);
+  for (int v = 0; v < A_V; ++v) gw += (v * NTHR + wave * 64 < BM * G::SLOTS) ? 1 : 0;
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        const int j = (wn * NT + nt) * 32 + r32;
-        w_off[nt][ks][t] = A_BYTES + j * G::ROWB + (((t * 4 + ks * 2 + h) ^ G::swz(j)) * 16);
+  for (int v = 0; v < W_V; ++v) gw += (v * NTHR + wave * 64 < BN * G::SLOTS) ? 1 : 0;
+  auto issue_next = [&](int bi) {
+    char* buf = ldsb + bi * BUF;
+    const char* src[UPS];
+    const char* wsrc[UPS];
+    uint32_t rowb[UPS];
+    int zero[UPS];
+    bool on[UPS];
+    const int k_before = it.k;
+#pragma unroll
+    for (int u = 0; u < UPS; ++u) {
+      on[u] = issued < nunit;
+      const bool first = it.cc < g0;
+      src[u] = (first ? a.s0 : a.s1) + (first ? it.cc : it.cc - g0) * GRPB;
+      rowb[u] = first ? rowb0 : rowb1;
+      zero[u] = (int)(first ? a.zero0 : a.zero1);
+      wsrc[u] = wsplit + ((uint64_t)it.k * wk_stride + (uint32_t)it.cc * GRPB);
+      if (on[u]) {
+        step(it);
+        ++issued;
       }
     }
+#pragma unroll
+    for (int v = 0; v < A_V; ++v) {
+      const bool u1 = UPS == 2 && a_u[v];
+      const int z = u1 ? zero[UPS - 1] : zero[0];
+      const uint32_t row = (uint32_t)(a_id[v] < 0 ? z : a_id[v]);
+      const char* g = (u1 ? src[UPS - 1] : src[0]) + ((uint64_t)row * (u1 ? rowb[UPS - 1] : rowb[0]) + a_p[v]);
+      if (A_EXACT || v * NTHR + wave * 64 < BM * G::SLOTS) {  // wave-uniform: this instruction exists for this wave
+        if (((A_EXACT && NO_DEAD) || a_on[v]) && (UPS == 1 || !u1 || on[UPS - 1]))
+          __builtin_amdgcn_global_load_lds(g, (lds_ptr_t)(buf + (v * NTHR + wave * 64) * 16), 16, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int v = 0; v < W_V; ++v) {
+      const bool u1 = UPS == 2 && w_u[v];
+      if (W_EXACT || v * NTHR + wave * 64 < BN * G::SLOTS) {
+        if (((W_EXACT && NO_DEAD) || w_on[v]) && (UPS == 1 || !u1 || on[UPS - 1]))
+          __builtin_amdgcn_global_load_lds((u1 ? wsrc[UPS - 1] : wsrc[0]) + w_o[v],
+                                           (lds_ptr_t)(buf + A_BYTES + (v * NTHR + wave * 64) * 16), 16, 0, 0);
+      }
+    }
+    // gathered rows of the next stage's units: with one unit per stage they only change with the kernel offset
+    if (issued < nunit && (UPS == 2 || it.k != k_before)) load_ids();
+  };
 
-  auto compute = [&](int bi) {
+  // fragment addresses (loop invariant): row of A / W this lane reads, with the swizzle applied per piece.
+  // Fragment q (0..3) is the pair of pieces 2q, 2q + 1 (one per half-wave): T = 2: q = 2 * term + k-step;
+  // T = 3: q = term; T = 1: q = 2 * unit + k-step.
+  constexpr int NQ = T == 3 ? 3 : 4;
+  const int r32 = lane & 31, h = lane >> 5;
+  const int arow = wm * 32 + r32;
+  uint32_t a_off[NQ], w_off[NT][NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    a_off[q] = arow * G::ROWB + (((2 * q + h) ^ G::swz(arow)) * 16);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int j = (wn * NT + nt) * 32 + r32;
+      w_off[nt][q] = A_BYTES + j * G::ROWB + (((2 * q + h) ^ G::swz(j)) * 16);
+    }
+  }
+
+  // matrix work of one stage; m0 / m1: this wave has pairs at the kernel offset of the stage's first / second unit
+  auto compute = [&](int bi, bool m0, bool m1) {
     const char* buf = ldsb + bi * BUF;
-    // products (activation term, weight term), smallest first: T = 2 -> (0,1) (1,0) (0,0); T = 3 adds (0,2) (2,0) (1,1)
-    constexpr int NP = T == 2 ? 3 : 6;
-    constexpr int pa[6] = {0, 2, 1, 0, 1, 0}, pb[6] = {2, 0, 1, 1, 0, 0};
+    if constexpr (T == 1) {
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 af[T];
+      for (int u = 0; u < 2; ++u) {
+        if (u == 0 ? !m0 : !m1) continue;
 #pragma unroll
-      for (int t = 0; t < T; ++t) af[t] = *reinterpret_cast<const bf16x8*>(buf + a_off[ks][t]);
+        for (int ks = 0; ks < 2; ++ks) {
+          const bf16x8 af = *reinterpret_cast<const bf16x8*>(buf + a_off[u * 2 + ks]);
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            const bf16x8 bf = *reinterpret_cast<const bf16x8*>(buf + w_off[nt][u * 2 + ks]);
+            acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[0][nt], 0, 0, 0);
+          }
+        }
+      }
+    } else if constexpr (T == 2) {
+      if (!m0) return;
+      // products (activation term, weight term), smallest first: (0,1) (1,0) (0,0)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        bf16x8 af[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) af[t] = *reinterpret_cast<const bf16x8*>(buf + a_off[t * 2 + ks]);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          bf16x8 bf[2];
+#pragma unroll
+          for (int t = 0; t < 2; ++t) bf[t] = *reinterpret_cast<const bf16x8*>(buf + w_off[nt][t * 2 + ks]);
+          acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[1], acc[0][nt], 0, 0, 0);
+          acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[0], acc[0][nt], 0, 0, 0);
+          acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[0], acc[0][nt], 0, 0, 0);
+        }
+      }
+    } else {
+      if (!m0) return;
+      bf16x8 af[3];
+#pragma unroll
+      for (int t = 0; t < 3; ++t) af[t] = *reinterpret_cast<const bf16x8*>(buf + a_off[t]);
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
-        bf16x8 bf[T];
+        bf16x8 bf[3];
 #pragma unroll
-        for (int t = 0; t < T; ++t) bf[t] = *reinterpret_cast<const bf16x8*>(buf + w_off[nt][ks][t]);
-#pragma unroll
-        for (int q = 6 - NP; q < 6; ++q)
-          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[pa[q]], bf[pb[q]], acc[nt], 0, 0, 0);
+        for (int t = 0; t < 3; ++t) bf[t] = *reinterpret_cast<const bf16x8*>(buf + w_off[nt][t]);
+        // the five products of relative size 2^-8 and below go to their own accumulator, smallest first
+        acc[NACC - 1][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[2], acc[NACC - 1][nt], 0, 0, 0);
+        acc[NACC - 1][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], bf[0], acc[NACC - 1][nt], 0, 0, 0);
+        acc[NACC - 1][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[1], acc[NACC - 1][nt], 0, 0, 0);
+        acc[NACC - 1][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[1], acc[NACC - 1][nt], 0, 0, 0);
+        acc[NACC - 1][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[0], acc[NACC - 1][nt], 0, 0, 0);
+        acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[0], acc[0][nt], 0, 0, 0);
       }
     }
   };
 
   if (nstage > 0) {
-    // Ring of NBUF buffers, stage s lives in buffer s % NBUF.  The requests of stages s + 1 .. s + NBUF - 2
-    // may still be in flight when stage s is consumed; the buffer that stage s - 1 just released receives
-    // stage s + NBUF - 1.  One barrier per stage: it publishes stage s to every wave and, because every wave
-    // has then finished reading stage s - 1, frees that buffer.
-    constexpr int G = A_V + W_V;  // DMA instructions per wave and stage
-    static_assert((NBUF - 2) * G < 64, "vmcnt is a 6-bit counter");
+    // Ring of NBUF buffers, stage s lives in buffer s % NBUF.  The requests of up to NBUF - 2 later stages may still
+    // be in flight when stage s is consumed; the buffer that stage s - 1 just released receives stage s + NBUF - 1.
+    // One barrier per stage: it publishes stage s to every wave and, because every wave has then finished reading
+    // stage s - 1, frees that buffer.  Every wave issues gw DMA instructions per stage, in stage order, so "all but
+    // the last j * gw have landed" retires exactly the stages up to s.
+    int bi_issue = 0;
 #pragma unroll
     for (int u = 0; u < NBUF - 1; ++u)
-      if (u < nstage) issue_next(u);
-    uint32_t crem = bmask;
-    int ck = __builtin_ctz(crem), ccc = 0;
-    for (int s0 = 0; s0 < nstage; s0 += NBUF) {
-#pragma unroll
-      for (int u = 0; u < NBUF; ++u) {
-        const int s = s0 + u;
-        if (s >= nstage) break;
-        const int ahead = nstage - 1 - s;  // stages issued after s (at most NBUF - 2 of them)
-        if (NBUF >= 4 && ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF >= 4 ? 2 : 0) * G) : "memory");
-        else if (NBUF >= 3 && ahead >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF >= 3 ? 1 : 0) * G) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (issued < nstage) issue_next((u + NBUF - 1) % NBUF);
-        if ((wmask >> ck) & 1u) compute(u);
-        if (++ccc == nchunk) {
-          ccc = 0;
-          crem &= crem - 1;
-          ck = crem ? __builtin_ctz(crem) : ck;
-        }
+      if (u < nstage) {
+        issue_next(u);
+        bi_issue = u + 1;
       }
+    if (bi_issue == NBUF) bi_issue = 0;
+    UnitIt ct{bmask, __builtin_ctz(bmask), 0};
+    int done = 0;  // units consumed so far
+    int bi = 0;
+#ifdef M3D_STAMP
+    unsigned long long st_wait = 0, st_issue = 0, st_comp = 0;
+#endif
+    for (int s = 0; s < nstage; ++s) {
+#ifdef M3D_STAMP
+      M3D_T(t0);
+#endif
+      const int ahead = nstage - 1 - s;  // later stages already requested: min(ahead, NBUF - 2)
+      if (NBUF >= 4 && ahead >= 2) {
+        if (gw == 7) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+        else if (gw == 6) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else if (gw == 5) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        else if (gw == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (gw == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else if (gw == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      } else if (NBUF >= 3 && ahead >= 1) {
+        if (gw == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+        else if (gw == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else if (gw == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        else if (gw == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (gw == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else if (gw == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+#ifdef M3D_STAMP
+      M3D_T(t1);
+#endif
+      if (issued < nunit) {
+        issue_next(bi_issue);
+        if (++bi_issue == NBUF) bi_issue = 0;
+      }
+#ifdef M3D_STAMP
+      M3D_T(t2);
+#endif
+      const bool m0 = (wmask >> ct.k) & 1u;
+      step(ct);
+      ++done;
+      bool m1 = false;
+      if (UPS == 2 && done < nunit) {
+        m1 = (wmask >> ct.k) & 1u;
+        step(ct);
+        ++done;
+      }
+      compute(bi, m0, m1);
+#ifdef M3D_STAMP
+      M3D_T(t3);
+      st_wait += t1 - t0; st_issue += t2 - t1; st_comp += t3 - t2;
+#endif
+      if (++bi == NBUF) bi = 0;
     }
+#ifdef M3D_STAMP
+    if (lane == 0) {
+      atomicAdd(&m3d_stamp_sums[0], st_wait);
+      atomicAdd(&m3d_stamp_sums[1], st_issue);
+      atomicAdd(&m3d_stamp_sums[2], st_comp);
+      atomicAdd(&m3d_stamp_sums[3], (unsigned long long)nstage);
+    }
+#endif
+  }
+  if constexpr (NACC == 2) {
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) acc[0][i][j] += acc[1][i][j];
   }
   if (a.slab) {
-    conv_epilogue<NT>(a, acc, orow_s, tile_base, col_base, wm, wn, lane);
+    conv_epilogue<NT>(a, acc[0], orow_s, tile_base, col_base, wm, wn, lane);
   } else {
     __syncthreads();  // every wave is done with the staging buffers; reuse them for the output tile
-    conv_epilogue_staged<WM, WN, NT>(a, acc, orow_s, reinterpret_cast<float*>(ldsb), col_base, wm, wn, lane, tid);
+    conv_epilogue_staged<WM, WN, NT>(a, acc[0], orow_s, reinterpret_cast<float*>(ldsb), col_base, wm, wn, lane, tid);
   }
 }
 
@@ -558,7 +720,8 @@ __global__ void split_f32_kernel(const float* __restrict__ in, int64_t n, int c,
 
 // Reference layout [Cout][k][Cin] f32 -> kernel layouts.
 //   terms == 0: [k][Cout][Cin] f32
-//   terms == 2/3: [k][Cout][Cin/32][terms][32] bf16 (term t = bf16 rounding of the remainder)
+//   terms == 1/2/3: [k][Cout][Cin/G][terms][G] bf16 (term t = bf16 rounding of the remainder; G = 16 for three
+//   terms, 32 otherwise)
 // transposed != 0: the packed weight is W'[o][k][c] = w[c][flip ? kvol - 1 - k : k][o] (w has the reference layout
 // [cin'][kvol][cout'] of the layer it came from; cout/cin below are those of W'): the weight of the input-gradient
 // convolution, formed without a transposed copy of w.
@@ -575,11 +738,12 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, int cout, int kv
     static_cast<float*>(out)[((int64_t)k * cout + o) * cin + c] = x;
     return;
   }
+  const int gs = split_group_shift(terms), g = 1 << gs;
   __bf16* dst = static_cast<__bf16*>(out) +
-                ((((int64_t)k * cout + o) * (cin / 32) + c / 32) * terms) * 32 + (c & 31);
+                (((((int64_t)k * cout + o) * (cin >> gs) + (c >> gs)) * terms) << gs) + (c & (g - 1));
   for (int t = 0; t < terms; ++t) {
     const __bf16 q = (__bf16)x;
-    dst[t * 32] = q;
+    dst[t * g] = q;
     x -= (float)q;
   }
 }
@@ -661,18 +825,19 @@ __global__ __launch_bounds__(256) void conv_rowwise_f32_kernel(ConvArgs a) {
       for (int i = 0; i < CO; ++i) o[i] = v[i];
     }
   }
-  if (a.out_split) {  // CO == 32: exactly one channel group
-    char* base = a.out_split + (((int64_t)orow * (a.cout >> 5) + (co_base >> 5)) * a.terms) * 64;
-    for (int tt = 0; tt < a.terms; ++tt) {
+  if (a.out_split) {
+    const int tstride = 2 << split_group_shift(a.terms);
 #pragma unroll
-      for (int o8 = 0; o8 < CO / 8; ++o8) {
+    for (int o8 = 0; o8 < CO / 8; ++o8) {
+      char* base = split_ptr(a.out_split, orow, co_base + o8 * 8, a.cout, a.terms);
+      for (int tt = 0; tt < a.terms; ++tt) {
         bf16x8 q;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
           q[i] = (__bf16)v[o8 * 8 + i];
           v[o8 * 8 + i] -= (float)q[i];
         }
-        *reinterpret_cast<bf16x8*>(base + tt * 64 + o8 * 16) = q;
+        *reinterpret_cast<bf16x8*>(base + tt * tstride) = q;
       }
     }
   }
@@ -720,12 +885,8 @@ template <int WM, int WN, int NT>
 static int launch_igemm(const ConvArgs& a, int nz, hipStream_t stream) {
   constexpr int BM = 32 * WM, BN = 32 * NT * WN, NTHR = 64 * WM * WN;
   const size_t lds = (size_t)(2 * (BM + BN) * kLdr) * sizeof(float) + BM * sizeof(int);
-  static bool attr_done = false;
-  if (!attr_done) {
-    M3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_f32_kernel<WM, WN, NT>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_done = true;
-  }
+  static LdsGrant grant;
+  if (int rc = grant.ensure(reinterpret_cast<const void*>(&conv_igemm_f32_kernel<WM, WN, NT>), lds)) return rc;
   dim3 grid((unsigned)(a.npad / BM), (unsigned)(a.cout / BN), (unsigned)nz);
   hipLaunchKernelGGL((conv_igemm_f32_kernel<WM, WN, NT>), grid, dim3(NTHR), lds, stream, a);
   M3D_LAUNCH_CHECK();
@@ -736,12 +897,8 @@ template <int WM, int WN, int NT, int T>
 static int launch_split(const ConvArgs& a, int nz, hipStream_t stream) {
   constexpr int BM = 32 * WM, BN = 32 * NT * WN, NTHR = 64 * WM * WN;
   const size_t lds = (size_t)2 * T * (BM + BN) * kRowB + BM * sizeof(int);
-  static bool attr_done = false;
-  if (!attr_done) {
-    M3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_split_kernel<WM, WN, NT, T>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_done = true;
-  }
+  static LdsGrant grant;
+  if (int rc = grant.ensure(reinterpret_cast<const void*>(&conv_igemm_split_kernel<WM, WN, NT, T>), lds)) return rc;
   dim3 grid((unsigned)(a.npad / BM), (unsigned)(a.cout / BN), (unsigned)nz);
   hipLaunchKernelGGL((conv_igemm_split_kernel<WM, WN, NT, T>), grid, dim3(NTHR), lds, stream, a);
   M3D_LAUNCH_CHECK();
@@ -753,34 +910,30 @@ static int launch_dma_n(const ConvArgs& a, int nz, hipStream_t stream) {
   constexpr int BM = 32 * WM, BN = 32 * NT * WN, NTHR = 64 * WM * WN;
   constexpr size_t ring = (size_t)NBUF * (BM + BN) * DmaGeom<T>::ROWB, tile = (size_t)BM * BN * sizeof(float);
   const size_t lds = (ring > tile ? ring : tile) + (size_t)(a.kvol + 1) * BM * sizeof(int);
-  static size_t attr_lds = 0;
-  if (lds > attr_lds) {
-    M3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_dma_kernel<WM, WN, NT, T, NBUF>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_lds = lds;
-  }
+  static LdsGrant grant;
+  if (int rc = grant.ensure(reinterpret_cast<const void*>(&conv_igemm_dma_kernel<WM, WN, NT, T, NBUF>), lds)) return rc;
   dim3 grid((unsigned)(a.npad / BM), (unsigned)(a.cout / BN), (unsigned)nz);
   hipLaunchKernelGGL((conv_igemm_dma_kernel<WM, WN, NT, T, NBUF>), grid, dim3(NTHR), lds, stream, a);
   M3D_LAUNCH_CHECK();
   return M3D_OK;
 }
 
-// Ring depth: as deep as 160 KB of LDS allow (experiment hook: M3D_NBUF).
+// Ring depth: two buffers everywhere.  A third (which the 96-byte rows of the three-term format leave room for at two
+// workgroups per CU) measured 4 % slower on the largest level: the stage loop is bound by the issue of its DMA
+// instructions (about 160 cycles each beside the matrix work of the other waves), not by their latency.
+// Experiment hook: M3D_NBUF.
 template <int WM, int WN, int NT, int T>
 static int launch_dma(const ConvArgs& a, int nz, hipStream_t stream) {
   constexpr int BM = 32 * WM, BN = 32 * NT * WN;
   static const int want = [] {
     const char* e = getenv("M3D_NBUF");
-    return e ? atoi(e) : 2;
+    return e ? atoi(e) : 0;
   }();
+  int nbuf = want ? want : 2;
   const size_t per_buf = (size_t)(BM + BN) * DmaGeom<T>::ROWB, idx = (size_t)(a.kvol + 1) * BM * sizeof(int);
-  int nbuf = want;
   while (nbuf > 2 && nbuf * per_buf + idx > 160 * 1024) --nbuf;
-  constexpr int G = (BM + BN) * DmaGeom<T>::SLOTS / (64 * WM * WN);  // DMA instructions per wave and stage
-  if constexpr (2 * G < 64)
-    if (nbuf >= 4) return launch_dma_n<WM, WN, NT, T, 4>(a, nz, stream);
-  if constexpr (G < 64)
-    if (nbuf >= 3) return launch_dma_n<WM, WN, NT, T, 3>(a, nz, stream);
+  if (nbuf >= 4) return launch_dma_n<WM, WN, NT, T, 4>(a, nz, stream);
+  if (nbuf == 3) return launch_dma_n<WM, WN, NT, T, 3>(a, nz, stream);
   return launch_dma_n<WM, WN, NT, T, 2>(a, nz, stream);
 }
 
@@ -838,12 +991,13 @@ extern "C" size_t m3d_conv_workspace_bytes(int64_t n, int cout, int k) {
   return align_up((size_t)nz * npad * cout * sizeof(float));
 }
 
-// mode: 0 exact f32, 1/2 split-bf16 with in-kernel activation split (T = 2/3), 3/4 LDS-DMA on sf32 inputs (T = 2/3)
+// mode: 0 exact f32; 1/2/5 bf16 products with the f32 activations split inside the kernel (T = 2/3/1);
+// 3/4/6 LDS-DMA on sf32 inputs (T = 2/3/1)
 static int run_conv(ConvArgs& a, int mode, bool mfma_ok, void* d_ws, size_t ws_bytes, hipStream_t stream,
                     const char* who) {
   a.slab = nullptr;
   if (!mfma_ok) {
-    if (mode >= 3) {
+    if (mode == 3 || mode == 4 || mode == 6) {
       set_error("%s: channel counts must be multiples of 32", who);
       return M3D_EINVAL;
     }
@@ -868,7 +1022,8 @@ static int run_conv(ConvArgs& a, int mode, bool mfma_ok, void* d_ws, size_t ws_b
         a.cout % (32 * q.nt * q.wn) == 0 && a.npad % (32 * q.wm) == 0 && q.nz >= 1 && q.nz <= a.kvol)
       p = q;
   }
-  if (mode >= 3 && p.wm == 1 && p.wn == 3) p = ConvPlan{1, 1, 3, p.nz};  // equal DMA count per wave
+  const bool dma = mode == 3 || mode == 4 || mode == 6;
+  if (dma && p.wm == 1 && p.wn == 3) p = ConvPlan{1, 1, 3, p.nz};  // equal DMA count per wave
   if (p.nz > 1) {
     const size_t need = (size_t)p.nz * a.npad * a.cout * sizeof(float);
     if (d_ws == nullptr || ws_bytes < need) {
@@ -883,13 +1038,15 @@ static int run_conv(ConvArgs& a, int mode, bool mfma_ok, void* d_ws, size_t ws_b
     if (mode == 0) rc = launch_igemm<WM_, WN_, NT_>(a, p.nz, stream);               \
     else if (mode == 1) rc = launch_split<WM_, WN_, NT_, 2>(a, p.nz, stream);       \
     else if (mode == 2) rc = launch_split<WM_, WN_, NT_, 3>(a, p.nz, stream);       \
+    else if (mode == 5) rc = launch_split<WM_, WN_, NT_, 1>(a, p.nz, stream);       \
   }
 #define M3D_CASE_DMA(WM_, WN_, NT_)                                                 \
   if (p.wm == WM_ && p.wn == WN_ && p.nt == NT_) {                                  \
     if (mode == 3) rc = launch_dma<WM_, WN_, NT_, 2>(a, p.nz, stream);              \
     else if (mode == 4) rc = launch_dma<WM_, WN_, NT_, 3>(a, p.nz, stream);         \
+    else if (mode == 6) rc = launch_dma<WM_, WN_, NT_, 1>(a, p.nz, stream);         \
   }
-  if (mode < 3) {
+  if (!dma) {
     M3D_CASE(4, 1, 1) M3D_CASE(4, 1, 2) M3D_CASE(4, 1, 3) M3D_CASE(4, 1, 4)
     M3D_CASE(2, 2, 1) M3D_CASE(2, 2, 2) M3D_CASE(2, 1, 3) M3D_CASE(2, 1, 1)
     M3D_CASE(1, 4, 1) M3D_CASE(1, 3, 1) M3D_CASE(1, 2, 1) M3D_CASE(1, 1, 1)
@@ -953,9 +1110,9 @@ extern "C" int m3d_conv_fwd_f32(const float* d_in0, int c0, const float* d_in1, 
   M3D_CHECK_ARG(c0 > 0 && c1 >= 0 && cout > 0 && k >= 1 && k <= 27, "%s: bad channel/kernel sizes", who);
   M3D_CHECK_ARG((c1 == 0) == (d_in1 == nullptr), "%s: in1/c1 mismatch", who);
   M3D_CHECK_ARG(d_out == nullptr || ldo >= cout, "%s: ldo < cout", who);
-  M3D_CHECK_ARG(precision >= 0 && precision <= 2, "%s: unknown precision %d", who, precision);
-  M3D_CHECK_ARG(d_out_split == nullptr || ((out_terms == 2 || out_terms == 3) && cout % 32 == 0),
-                "%s: a split output needs out_terms in {2,3} and cout %% 32 == 0", who);
+  M3D_CHECK_ARG(precision >= 0 && precision <= 3, "%s: unknown precision %d", who, precision);
+  M3D_CHECK_ARG(d_out_split == nullptr || (out_terms >= 1 && out_terms <= 3 && cout % 32 == 0),
+                "%s: a split output needs out_terms in {1,2,3} and cout %% 32 == 0", who);
   if (int rc = check_schedule(d_nbr, d_out_row, d_tile_mask, k, n, &npad, who)) return rc;
   ConvArgs a = {};
   a.in0 = d_in0; a.in1 = d_in1; a.weight = d_weight; a.nbr = d_nbr; a.out_row = d_out_row;
@@ -965,7 +1122,11 @@ extern "C" int m3d_conv_fwd_f32(const float* d_in0, int c0, const float* d_in1, 
   a.out_split = static_cast<char*>(d_out_split); a.terms = out_terms;
   a.tile_order = d_tile_order;
   const bool mfma_ok = (c0 % 32 == 0) && (c1 % 32 == 0) && (cout % 32 == 0);
-  return run_conv(a, precision, mfma_ok, d_ws, ws_bytes, stream, who);
+  // a weight packed for a bf16 precision is bf16 only where the whole layer runs on the matrix cores: two input
+  // slabs whose sum is a multiple of 32 but which are not multiples themselves have no kernel
+  M3D_CHECK_ARG(precision == M3D_PREC_F32 || mfma_ok || (c0 + c1) % 32 != 0 || cout % 32 != 0,
+                "%s: with a bf16 precision both input slabs (%d, %d) must be multiples of 32 channels", who, c0, c1);
+  return run_conv(a, precision == M3D_PREC_BF16 ? 5 : precision, mfma_ok, d_ws, ws_bytes, stream, who);
 }
 
 extern "C" int m3d_conv_fwd_sf32(const void* d_in0, int c0, int64_t rows0, const void* d_in1, int c1,
@@ -981,7 +1142,7 @@ extern "C" int m3d_conv_fwd_sf32(const void* d_in0, int c0, int64_t rows0, const
   M3D_CHECK_ARG(n >= 0, "%s: n < 0", who);
   if (n == 0) return M3D_OK;
   M3D_CHECK_ARG(d_in0 && d_weight && (d_out || d_out_split), "%s: null pointer", who);
-  M3D_CHECK_ARG(terms == 2 || terms == 3, "%s: terms must be 2 or 3", who);
+  M3D_CHECK_ARG(terms >= 1 && terms <= 3, "%s: terms must be 1, 2 or 3", who);
   M3D_CHECK_ARG(c0 > 0 && c1 >= 0 && cout > 0 && k >= 1 && k <= 27, "%s: bad channel/kernel sizes", who);
   M3D_CHECK_ARG(c0 % 32 == 0 && c1 % 32 == 0 && cout % 32 == 0, "%s: channel counts must be multiples of 32", who);
   M3D_CHECK_ARG((c1 == 0) == (d_in1 == nullptr), "%s: in1/c1 mismatch", who);
@@ -1004,7 +1165,7 @@ extern "C" int m3d_conv_fwd_sf32(const void* d_in0, int c0, int64_t rows0, const
     return run_conv_halo(a, d_halo_cnt, d_halo_rows, d_halo_loc, d_halo_order, stream);
   }
   a.tile_order = d_tile_order;
-  return run_conv(a, terms == 2 ? 3 : 4, true, d_ws, ws_bytes, stream, who);
+  return run_conv(a, terms == 2 ? 3 : (terms == 3 ? 4 : 6), true, d_ws, ws_bytes, stream, who);
 }
 
 extern "C" size_t m3d_sf32_bytes(int64_t n, int c, int terms) {
@@ -1013,7 +1174,7 @@ extern "C" size_t m3d_sf32_bytes(int64_t n, int c, int terms) {
 
 extern "C" int m3d_split_f32(const float* d_in, int64_t n, int c, int terms, void* d_out, void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
-  M3D_CHECK_ARG(d_in && d_out && n >= 0 && c > 0 && c % 32 == 0 && (terms == 2 || terms == 3),
+  M3D_CHECK_ARG(d_in && d_out && n >= 0 && c > 0 && c % 32 == 0 && terms >= 1 && terms <= 3,
                 "m3d_split_f32: bad arguments");
   const int64_t total = (n + 1) * c;
   hipLaunchKernelGGL(split_f32_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, stream, d_in, n, c, terms,
@@ -1026,16 +1187,17 @@ extern "C" size_t m3d_conv_packed_weight_bytes(int cout, int k, int cin, int pre
   const bool mfma_ok = cin % 32 == 0 && cout % 32 == 0;
   const size_t elems = (size_t)cout * k * cin;
   if (precision == M3D_PREC_F32 || !mfma_ok) return elems * sizeof(float);
-  return elems * 2 * (precision == M3D_PREC_BF16X3 ? 2 : 3);
+  return elems * 2 * (precision == M3D_PREC_BF16X3 ? 2 : (precision == M3D_PREC_BF16X6 ? 3 : 1));
 }
 
 static int pack_weight_launch(const char* who, const float* d_weight_ref, int cout, int k, int cin, int precision,
                               int transposed, int flip, void* d_out, void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   M3D_CHECK_ARG(d_weight_ref && d_out && cout > 0 && k > 0 && cin > 0, "%s: bad arguments", who);
-  M3D_CHECK_ARG(precision >= 0 && precision <= 2, "%s: unknown precision %d", who, precision);
+  M3D_CHECK_ARG(precision >= 0 && precision <= 3, "%s: unknown precision %d", who, precision);
   const bool mfma_ok = cin % 32 == 0 && cout % 32 == 0;
-  const int terms = (precision == M3D_PREC_F32 || !mfma_ok) ? 0 : (precision == M3D_PREC_BF16X3 ? 2 : 3);
+  const int terms = (precision == M3D_PREC_F32 || !mfma_ok) ? 0
+                    : (precision == M3D_PREC_BF16X3 ? 2 : (precision == M3D_PREC_BF16X6 ? 3 : 1));
   const int64_t total = (int64_t)cout * k * cin;
   hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, stream, d_weight_ref,
                      cout, k, cin, terms, transposed, flip, d_out);
@@ -1054,3 +1216,12 @@ extern "C" int m3d_conv_pack_weight_transposed(const float* d_weight_ref, int co
   return pack_weight_launch("m3d_conv_pack_weight_transposed", d_weight_ref, cin, k, cout, precision, 1, flip != 0,
                             d_out, stream);
 }
+
+#ifdef M3D_STAMP
+extern "C" int m3d_debug_stamps(unsigned long long* out8, int reset) {
+  unsigned long long z[8] = {};
+  if (out8 && hipMemcpyFromSymbol(out8, HIP_SYMBOL(m3d::m3d_stamp_sums), sizeof(z)) != hipSuccess) return -3;
+  if (reset && hipMemcpyToSymbol(HIP_SYMBOL(m3d::m3d_stamp_sums), z, sizeof(z)) != hipSuccess) return -3;
+  return 0;
+}
+#endif

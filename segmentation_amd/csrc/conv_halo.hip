@@ -489,12 +489,8 @@ static int launch_halo(const ConvArgs& a, const HaloArgs& hl, hipStream_t stream
   static_assert(lds <= 160 * 1024, "LDS budget");
   static_assert((size_t)kHaloRows * BN * 4 <= (size_t)(kHaloCap + 1) * G::ROWB + (size_t)NW * BN * G::ROWB,
                 "output tile must fit in the halo + weight regions");
-  static bool attr_done = false;
-  if (!attr_done) {
-    M3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_kernel<NT, NW>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_done = true;
-  }
+  static LdsGrant grant;
+  if (int rc = grant.ensure(reinterpret_cast<const void*>(&conv_halo_kernel<NT, NW>), lds)) return rc;
   dim3 grid((unsigned)(a.npad / kHaloRows), (unsigned)(a.cout / BN), 1);
   hipLaunchKernelGGL((conv_halo_kernel<NT, NW>), grid, dim3(256), lds, stream, a, hl);
   M3D_LAUNCH_CHECK();

@@ -20,7 +20,8 @@ struct ConvArgs {
   float* slab;  // split-K partial sums [z][npad][cout], or nullptr
   int64_t n, npad, ldo;
   int c0, c1, cout, kvol, relu;
-  // split-format ("sf32") operands of the LDS-DMA kernel: [rows + 1][C/32][T][32] bf16, last row zero
+  // split-format ("sf32") operands of the LDS-DMA kernel: [rows + 1][C/G][T][G] bf16 (G = 16 for T = 3, else 32),
+  // last row zero
   const char* s0;
   const char* s1;
   int64_t zero0, zero1;  // index of the all-zero row of s0 / s1
@@ -32,12 +33,24 @@ struct ConvArgs {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
-// One element of an sf32 tensor: term t = bf16 rounding of what the earlier terms left over.
+// Split format ("sf32") of an [rows, c] tensor with T terms: [rows + 1][c/G][T][G] bf16, G = 16 channels per group
+// for T = 3 and 32 otherwise (T = 1 is plain row-major bf16); term t = bf16 rounding of what the earlier terms left
+// over; row `rows` is all zero.  split_group_shift(T) = log2 G; split_ptr = address of term 0 of (row, col), the other
+// terms follow at a stride of 2 G bytes.
+__host__ __device__ inline int split_group_shift(int terms) { return terms == 3 ? 4 : 5; }
+
+__device__ inline char* split_ptr(char* base, int64_t row, int col, int c, int terms) {
+  const int gs = split_group_shift(terms);
+  return base + (((row * (c >> gs) + (col >> gs)) * terms) << (gs + 1)) + ((col & ((1 << gs) - 1)) << 1);
+}
+
+// One element of an sf32 tensor.
 __device__ inline void store_split(char* base, int64_t row, int col, int c, int terms, float v) {
-  __bf16* p = reinterpret_cast<__bf16*>(base + ((row * (c >> 5) + (col >> 5)) * terms) * 64) + (col & 31);
+  __bf16* p = reinterpret_cast<__bf16*>(split_ptr(base, row, col, c, terms));
+  const int g = 1 << split_group_shift(terms);
   for (int t = 0; t < terms; ++t) {
     const __bf16 q = (__bf16)v;
-    p[t * 32] = q;
+    p[t * g] = q;
     v -= (float)q;
   }
 }
@@ -133,7 +146,8 @@ __device__ inline void conv_store_tile(const ConvArgs& a, const float* S, const 
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], 0.f);
       }
-      char* base = a.out_split + (((int64_t)orow * (a.cout >> 5) + (col >> 5)) * a.terms) * 64 + (col & 31) * 2;
+      char* base = split_ptr(a.out_split, orow, col, a.cout, a.terms);
+      const int tstride = 2 << split_group_shift(a.terms);
       for (int t = 0; t < a.terms; ++t) {
         bf16x8 q;
 #pragma unroll
@@ -141,7 +155,7 @@ __device__ inline void conv_store_tile(const ConvArgs& a, const float* S, const 
           q[i] = (__bf16)v[i];
           v[i] -= (float)q[i];
         }
-        *reinterpret_cast<bf16x8*>(base + t * 64) = q;
+        *reinterpret_cast<bf16x8*>(base + t * tstride) = q;
       }
     }
     return;
@@ -172,7 +186,8 @@ __device__ inline void conv_store_tile(const ConvArgs& a, const float* S, const 
       }
     }
     if (a.out_split) {
-      char* base = a.out_split + (((int64_t)orow * (a.cout >> 5) + (col >> 5)) * a.terms) * 64 + (col & 31) * 2;
+      char* base = split_ptr(a.out_split, orow, col, a.cout, a.terms);
+      const int tstride = 2 << split_group_shift(a.terms);
       for (int t = 0; t < a.terms; ++t) {
         bf16x4 q;
 #pragma unroll
@@ -180,7 +195,7 @@ __device__ inline void conv_store_tile(const ConvArgs& a, const float* S, const 
           q[i] = (__bf16)v[i];
           v[i] -= (float)q[i];
         }
-        *reinterpret_cast<bf16x4*>(base + t * 64) = q;
+        *reinterpret_cast<bf16x4*>(base + t * tstride) = q;
       }
     }
   }
@@ -237,14 +252,23 @@ __device__ inline void conv_masks(const ConvArgs& a, int64_t tile_base, int wm, 
 constexpr int kBK = 32;
 constexpr int kLdr = 36;  // LDS row stride in floats
 
-// LDS image geometry of the LDS-DMA kernels: one (row, 32-channel group) is SLOTS 16-byte pieces, T terms x 4
-// pieces used; piece p of row r sits in slot p ^ swz(r), which keeps ds_read_b128 fragment reads conflict-free.
+// LDS image geometry of the LDS-DMA kernels.  The reduction runs over units = (kernel offset, channel group of G
+// channels); a unit of one row is PIECES 16-byte pieces in HBM (all terms of the group, contiguous).  An LDS row is
+// T = 2: one unit of 32 channels (8 pieces, 128 bytes); T = 1: two consecutive units of 32 channels (4 pieces each,
+// 128 bytes), so that a stage carries as much matrix work per byte as the others; T = 3: one unit of 16 channels
+// (6 pieces, 96 bytes).  Piece p of row r sits in slot p ^ swz(r), which keeps ds_read_b128 fragment reads
+// conflict-free although the image is written lane-linearly by the DMA: a ds_read_b128 serves 16 lanes at a time,
+// whose rows cover every residue mod 16; with 128-byte rows two rows share a 256-byte bank line and the eight
+// row pairs take the eight XOR patterns; with 96-byte rows the rows r and r + 8 start on the same banks and take
+// the two slots of a piece pair.
 template <int T>
 struct DmaGeom {
-  static constexpr int SLOTS = T == 2 ? 8 : 16;
-  static constexpr int PIECES = 4 * T;
+  static constexpr int G = T == 3 ? 16 : 32;   // channels per unit
+  static constexpr int UPS = T == 1 ? 2 : 1;   // units per stage
+  static constexpr int PIECES = T == 1 ? 4 : (T == 2 ? 8 : 6);
+  static constexpr int SLOTS = T == 3 ? 6 : 8;
   static constexpr int ROWB = SLOTS * 16;
-  __device__ static inline int swz(int r) { return T == 2 ? ((r >> 1) & 7) : (r & 15); }
+  __device__ static inline int swz(int r) { return T == 3 ? ((r >> 3) & 1) : ((r >> 1) & 7); }
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;

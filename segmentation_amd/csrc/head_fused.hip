@@ -328,12 +328,8 @@ template <int G1, int NT2, int NW>
 static int launch_head(const HeadArgs& a, hipStream_t stream) {
   constexpr int BUF = (32 * G1 + 32 * NT2) * DmaGeom<2>::ROWB;
   const size_t lds = 3 * (size_t)BUF;
-  static size_t attr_lds = 0;
-  if (lds > attr_lds) {
-    M3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&head_fused_kernel<G1, NT2, NW>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_lds = lds;
-  }
+  static LdsGrant grant;
+  if (int rc = grant.ensure(reinterpret_cast<const void*>(&head_fused_kernel<G1, NT2, NW>), lds)) return rc;
   // rounds of one workgroup per CU; what is left after the full rounds goes out in pieces small enough for one round
   static const int ncu = [] {
     int dev = 0, v = 0;

@@ -74,7 +74,7 @@ class SpUNetEngine:
         # levels whose submanifold convolutions run on the halo kernel (spatially compact Morton tiles)
         self.halo_levels = [int(m) for m in os.environ.get("M3D_HALO_LEVELS", "").split(",") if m != ""]
         self.halo_mode = int(os.environ.get("M3D_HALO_MODE", "1"))
-        self._terms = {"f32": 0, "bf16x3": 2, "bf16x6": 3}[precision]
+        self._terms = ops.TERMS[precision]
         # with a split precision `final` also writes an sf32 copy of the features for the logits GEMM
         self.head_precision = precision
         self.fuse_head = os.environ.get("M3D_FUSE_HEAD", "1") != "0"

@@ -253,7 +253,9 @@ def build_schedule(pair, n, indices=None, mode=0, spatial_shape=None, batch_size
 
 
 # ----------------------------------------------------------------------------- convolution
-PRECISION = {"f32": 0, "bf16x3": 1, "bf16x6": 2}
+PRECISION = {"f32": 0, "bf16x3": 1, "bf16x6": 2, "bf16": 3}
+TERMS = {"f32": 0, "bf16": 1, "bf16x3": 2, "bf16x6": 3}          # terms of the split format each precision consumes
+PRECISION_OF_TERMS = {1: "bf16", 2: "bf16x3", 3: "bf16x6"}
 
 
 @dataclass
@@ -295,7 +297,7 @@ def pack_weight(weight, precision="f32", device=None, transposed=False, flip=Fal
 @dataclass
 class SplitTensor:
     """An f32 [n, c] tensor in the engine-internal split format "sf32" (see include/m3d.h):
-    [n + 1][c/32][terms][32] bf16, row n all zero."""
+    [n + 1][c/G][terms][G] bf16 (G = 16 for three terms, else 32; one term = plain bf16 rows), row n all zero."""
     data: torch.Tensor  # uint8
     n: int
     c: int
@@ -319,7 +321,8 @@ def split_f32(x, terms):
 
 def unsplit(st: SplitTensor):
     """sf32 -> f32 (sum of the terms); for tests and debugging."""
-    v = st.data.view(torch.bfloat16).view(st.n + 1, st.c // 32, st.terms, 32).float().sum(2)
+    g = 16 if st.terms == 3 else 32
+    v = st.data.view(torch.bfloat16).view(st.n + 1, st.c // g, st.terms, g).float().sum(2)
     return v.reshape(st.n + 1, st.c)[:st.n]
 
 
@@ -329,7 +332,7 @@ def conv_fwd(in0, weight_packed: PackedWeight, sched: Optional[Schedule], n_out,
 
     sched=None is the dense 1x1 case (Custom1x1Subm3d, structure.py:336-347).  in0/in1 are f32 tensors or
     SplitTensors (then the LDS-DMA kernel runs; the weight must be packed for the matching precision).
-    Returns the f32 output, or (f32 output or None, SplitTensor) when split_terms is 2 or 3."""
+    Returns the f32 output, or (f32 output or None, SplitTensor) when split_terms is 1, 2 or 3."""
     lib = _lib.load()
     sf_in = isinstance(in0, SplitTensor)
     k, cout, cin = weight_packed.k, weight_packed.cout, weight_packed.cin
@@ -338,7 +341,7 @@ def conv_fwd(in0, weight_packed: PackedWeight, sched: Optional[Schedule], n_out,
     if c0 + c1 != cin:
         raise ValueError(f"input channels {c0}+{c1} do not match the weight's {cin}")
     if sf_in:
-        want = {2: "bf16x3", 3: "bf16x6"}[in0.terms]
+        want = PRECISION_OF_TERMS[in0.terms]
         if weight_packed.precision != want:
             raise ValueError(f"sf32 input with {in0.terms} terms needs a weight packed for {want}")
         if in1 is not None and not (isinstance(in1, SplitTensor) and in1.terms == in0.terms):
@@ -350,8 +353,8 @@ def conv_fwd(in0, weight_packed: PackedWeight, sched: Optional[Schedule], n_out,
         assert in0.is_contiguous() and in0.dtype == torch.float32
         assert in1 is None or (in1.is_contiguous() and in1.dtype == torch.float32)
         dev = in0.device
-    if split_terms not in (0, 2, 3):
-        raise ValueError("split_terms must be 0, 2 or 3")
+    if split_terms not in (0, 1, 2, 3):
+        raise ValueError("split_terms must be 0, 1, 2 or 3")
     if sf_in and split_terms and split_terms != in0.terms:
         raise ValueError("the split output of an sf32 convolution uses the input's number of terms")
     if not want_f32 and split_terms == 0:
@@ -398,7 +401,7 @@ def conv_fwd(in0, weight_packed: PackedWeight, sched: Optional[Schedule], n_out,
         ev0.record()
     osp = None if out_sp is None else out_sp.data
     hcnt = hrows = hloc = horder = None
-    if sf_in and sched is not None and sched.halo is not None and in0.terms == 2:
+    if sf_in and sched is not None and sched.halo is not None and in0.terms == 2:  # the halo kernel is two-term only
         hcnt, hrows, hloc, horder = sched.halo
     if sf_in:
         rc = lib.m3d_conv_fwd_sf32(_ptr(in0.data), c0, in0.n, _ptr(None if in1 is None else in1.data), c1,

@@ -10,7 +10,7 @@ from segmentation_amd import ops, scenes
 pytestmark = pytest.mark.gpu
 
 
-TOL = {"f32": 1e-5, "bf16x6": 1e-5, "bf16x3": 6e-5}
+TOL = {"f32": 1e-5, "bf16x6": 1e-5, "bf16x3": 6e-5, "bf16": 1e-2}
 
 
 def _rel(out, ref):
@@ -33,7 +33,7 @@ def level(device):
 
 
 # (cin, cout): every SubM shape of spunet34c plus odd shapes for the direct kernel
-@pytest.mark.parametrize("prec", ["f32", "bf16x6", "bf16x3"])
+@pytest.mark.parametrize("prec", ["f32", "bf16x6", "bf16x3", "bf16"])
 @pytest.mark.parametrize("cin,cout", [(3, 32), (32, 32), (64, 64), (96, 96), (128, 96), (128, 128),
                                         (192, 128), (256, 256), (384, 256), (6, 32), (40, 24)])
 def test_subm_conv(device, level, cin, cout, prec):
@@ -46,7 +46,7 @@ def test_subm_conv(device, level, cin, cout, prec):
     assert _rel(out, ref) < TOL[prec]
 
 
-@pytest.mark.parametrize("prec", ["f32", "bf16x6", "bf16x3"])
+@pytest.mark.parametrize("prec", ["f32", "bf16x6", "bf16x3", "bf16"])
 def test_subm_conv_fused_epilogue_and_two_sources(device, level, prec):
     g = torch.Generator().manual_seed(7)
     n = level["idx"].shape[0]
@@ -61,7 +61,7 @@ def test_subm_conv_fused_epilogue_and_two_sources(device, level, prec):
     assert _rel(out, ref) < TOL[prec]
 
 
-@pytest.mark.parametrize("prec", ["f32", "bf16x6", "bf16x3"])
+@pytest.mark.parametrize("prec", ["f32", "bf16x6", "bf16x3", "bf16"])
 @pytest.mark.parametrize("cin,cout", [(32, 32), (32, 64), (64, 128), (128, 256)])
 def test_strided_and_inverse_conv(device, level, cin, cout, prec):
     g = torch.Generator().manual_seed(cin + cout)
@@ -78,7 +78,7 @@ def test_strided_and_inverse_conv(device, level, cin, cout, prec):
     assert _rel(out_i, ref_i) < TOL[prec]
 
 
-@pytest.mark.parametrize("prec", ["f32", "bf16x6", "bf16x3"])
+@pytest.mark.parametrize("prec", ["f32", "bf16x6", "bf16x3", "bf16"])
 @pytest.mark.parametrize("n,cin,cout", [(5000, 96, 768), (700, 384, 256), (130, 128, 96), (1, 96, 32), (70000, 128, 96)])
 def test_dense_1x1_with_bias(device, n, cin, cout, prec):
     g = torch.Generator().manual_seed(n)
@@ -90,7 +90,7 @@ def test_dense_1x1_with_bias(device, n, cin, cout, prec):
     assert _rel(out, ref) < TOL[prec]
 
 
-@pytest.mark.parametrize("prec", ["f32", "bf16x6", "bf16x3"])
+@pytest.mark.parametrize("prec", ["f32", "bf16x6", "bf16x3", "bf16"])
 @pytest.mark.parametrize("target", [300, 1500, 30000])
 def test_all_tile_configurations(device, target, prec):
     """Small, medium and large levels pick different tile shapes / split-K; all must agree with the oracle."""

@@ -12,7 +12,8 @@ level, cin, cout = int(sys.argv[1].rstrip("duh")), int(sys.argv[2]), int(sys.arg
 plans = sys.argv[4:] or ["-"]
 os.environ["M3D_PLAN"] = "0,0,0,0"  # sizes the workspace for any split count; an invalid plan is ignored
 dev = torch.device("cuda:0")
-eng, model, cfg = bench.build_engine(dev, "bf16x3")
+prec = os.environ.get("PREC", "bf16x3")
+eng, model, cfg = bench.build_engine(dev, prec)
 sc = scenes.make_scene(seed=0, target_voxels=bench.TARGET_VOXELS)
 n = sc["coord"].shape[0]
 vox = ops.voxelize(torch.from_numpy(sc["coord"]).to(dev), torch.from_numpy(sc["feat"]).to(dev), np.array([0, n]), 0.02)
@@ -20,8 +21,8 @@ levels = eng.build_levels(vox["voxel_coords"], vox["spatial_shape"], 1)
 lv = levels[level]
 sched, N, n_in, k = {"s": (lv.subm, lv.n, lv.n, 27), "d": (lv.down, lv.n_next, lv.n, 8), "u": (lv.up, lv.n, lv.n_next, 8),
                      "h": (None, lv.n, lv.n, 1)}[kind]
-x = ops.split_f32(torch.randn(n_in, cin, device=dev), 2)
-w = ops.pack_weight(torch.randn(cout, k, cin) * 0.03, "bf16x3", dev)
+x = ops.split_f32(torch.randn(n_in, cin, device=dev), ops.TERMS[prec])
+w = ops.pack_weight(torch.randn(cout, k, cin) * 0.03, prec, dev)
 ref = None
 for plan in plans:
     os.environ["M3D_PLAN"] = "0,0,0,0" if plan == "-" else plan
@@ -39,4 +40,4 @@ for plan in plans:
     for _ in range(reps):
         ops.conv_fwd(x, w, sched, N)
     e1.record(); torch.cuda.synchronize()
-    print(f"level {level}{kind} n={N} {cin}->{cout} plan {plan:10s} {e0.elapsed_time(e1) / reps * 1e3:7.1f} us  rel diff {err:.2e}", flush=True)
+    print(f"{prec} level {level}{kind} n={N} {cin}->{cout} plan {plan:10s} {e0.elapsed_time(e1) / reps * 1e3:7.1f} us  rel diff {err:.2e}", flush=True)
