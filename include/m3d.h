@@ -71,6 +71,18 @@ int m3d_voxelize(const float* d_coord, const float* d_feat, const int64_t* d_off
                  uint64_t* d_keys, int32_t* d_grid_coord, int64_t* d_meta, void* d_ws,
                  size_t ws_bytes, void* stream);
 
+/* pooling_method = "random" of Point.sparsify (random_pooling, mosaic3d/src/models/utils/structure.py:69-110; selected
+ * through spconv_unet_v1m1_base.py:177-178, :335-339): voxel set, order and v2p_map are those of m3d_voxelize; the
+ * feature of a voxel is the feature of one of its points, drawn uniformly.  The reference draws with numpy's global
+ * RNG; here the draw is a function of (seed, point index), so a seed reproduces it.
+ *   d_v2p_map [n_pts] i64 (from m3d_voxelize), d_feat [n_pts, c] f32 (may be NULL with d_voxel_feats)
+ *   d_choice [n_vox] i64 chosen point of every voxel (may be NULL); d_voxel_feats [n_vox, c] f32 (may be NULL)
+ *   workspace: m3d_voxel_pick_random_workspace_bytes(n_vox); n_pts < 2^32 */
+size_t m3d_voxel_pick_random_workspace_bytes(int64_t n_vox);
+int m3d_voxel_pick_random(const int64_t* d_v2p_map, const float* d_feat, int64_t n_pts, int c, int64_t n_vox,
+                          uint64_t seed, int64_t* d_choice, float* d_voxel_feats, void* d_ws, size_t ws_bytes,
+                          void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * GridSample's deterministic part (mosaic3d/src/data/utils/transform.py:751-762, :813-826, :858-887):
  * grid = floor(float64(coord) / grid_size) - min, key = FNV64-1A or ravel over (x, y, z), voxels in ascending

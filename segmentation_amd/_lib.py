@@ -21,6 +21,8 @@ SIGNATURES = {
     "m3d_voxelize_workspace_bytes": (_sz, [_i64, _int]),
     "m3d_voxelize": (_int, [_vp, _vp, _vp, _i64, _int, _int, _f32, _int, _int, _int,
                             _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "m3d_voxel_pick_random_workspace_bytes": (_sz, [_i64]),
+    "m3d_voxel_pick_random": (_int, [_vp, _vp, _i64, _int, _i64, ctypes.c_uint64, _vp, _vp, _vp, _sz, _vp]),
     "m3d_grid_sample_workspace_bytes": (_sz, [_i64]),
     "m3d_grid_sample": (_int, [_vp, _i64, ctypes.c_double, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "m3d_stray_convert": (_int, [_vp, _vp, _i64, _vp, _vp, _vp]),

@@ -307,3 +307,59 @@ extern "C" int m3d_grid_sample(const float* d_coord, int64_t n, double grid_size
                        hash_type == M3D_HASH_FNV ? kHashFnv3 : M3D_HASH_RAVEL, kGridFloor64, d_voxel_coords, nullptr,
                        d_inverse, d_keys, d_grid_coord, d_count, d_meta, d_ws, ws_bytes, stream);
 }
+
+// ------------------------------------------------------------------------------------------
+// pooling_method = "random" (random_pooling, mosaic3d/src/models/utils/structure.py:69-110): the voxel set, its order
+// and v2p_map are those of mean pooling; the feature of a voxel is the feature of ONE of its points, drawn uniformly.
+// The reference draws with numpy's global RNG in a Python loop; here every point gets a 32-bit hash of (seed, point
+// index) and the point with the largest (hash, index) word of a voxel wins (one 64-bit atomic max per point).
+namespace m3d {
+
+__global__ __launch_bounds__(256) void pick_bid_kernel(const int64_t* __restrict__ v2p, int64_t n_pts, uint64_t seed,
+                                                       unsigned long long* __restrict__ best) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n_pts) return;
+  const uint64_t h = mix64(seed ^ ((uint64_t)p * 0x9E3779B97F4A7C15ull));
+  atomicMax(&best[v2p[p]], (unsigned long long)((h & 0xFFFFFFFF00000000ull) | (uint64_t)p));
+}
+
+__global__ __launch_bounds__(256) void pick_gather_kernel(const unsigned long long* __restrict__ best,
+                                                          const float* __restrict__ feat, int c, int64_t n_vox,
+                                                          int64_t* __restrict__ choice, float* __restrict__ voxel_feats) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_vox * c) return;
+  const int64_t v = e / c;
+  const int ch = (int)(e % c);
+  const int64_t p = (int64_t)(best[v] & 0xFFFFFFFFull);
+  if (ch == 0 && choice) choice[v] = p;
+  if (voxel_feats) voxel_feats[e] = feat[p * c + ch];
+}
+
+}  // namespace m3d
+
+extern "C" size_t m3d_voxel_pick_random_workspace_bytes(int64_t n_vox) {
+  return align_up((size_t)(n_vox > 0 ? n_vox : 1) * sizeof(unsigned long long));
+}
+
+extern "C" int m3d_voxel_pick_random(const int64_t* d_v2p_map, const float* d_feat, int64_t n_pts, int c,
+                                     int64_t n_vox, uint64_t seed, int64_t* d_choice, float* d_voxel_feats,
+                                     void* d_ws, size_t ws_bytes, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  const char* who = "m3d_voxel_pick_random";
+  M3D_CHECK_ARG(d_v2p_map && (d_choice || d_voxel_feats), "%s: null pointer", who);
+  M3D_CHECK_ARG(d_voxel_feats == nullptr || (d_feat != nullptr && c >= 1), "%s: features requested without an input", who);
+  M3D_CHECK_ARG(n_pts >= 1 && n_pts < ((int64_t)1 << 32) && n_vox >= 1 && n_vox <= n_pts, "%s: bad sizes", who);
+  const size_t need = (size_t)n_vox * sizeof(unsigned long long);
+  if (d_ws == nullptr || ws_bytes < need) {
+    set_error("%s: workspace too small (%zu given, %zu needed)", who, ws_bytes, need);
+    return M3D_ENOSPC;
+  }
+  unsigned long long* best = static_cast<unsigned long long*>(d_ws);
+  M3D_HIP(hipMemsetAsync(best, 0, need, stream));
+  hipLaunchKernelGGL(pick_bid_kernel, dim3((unsigned)cdiv(n_pts, 256)), dim3(256), 0, stream, d_v2p_map, n_pts, seed, best);
+  const int cc = d_voxel_feats ? c : 1;
+  hipLaunchKernelGGL(pick_gather_kernel, dim3((unsigned)cdiv(n_vox * cc, 256)), dim3(256), 0, stream, best, d_feat, cc,
+                     n_vox, d_choice, d_voxel_feats);
+  M3D_LAUNCH_CHECK();
+  return M3D_OK;
+}

@@ -53,8 +53,11 @@ def _shape3(shape: Sequence[int]):
 
 # ----------------------------------------------------------------------------- voxelize
 def voxelize(coord, feat, offset, grid_size, pad=128, hash_method="fnv", grid_mode="div",
-             return_keys=False, return_grid_coord=False):
-    """Point.sparsify + mean_pooling on the GPU (reference: structure.py:197-251, :34-66).
+             return_keys=False, return_grid_coord=False, pooling_method="mean", seed=0):
+    """Point.sparsify + mean_pooling / random_pooling on the GPU (reference: structure.py:197-251, :34-110).
+
+    pooling_method="random" keeps the voxel set, order and v2p_map and takes every voxel's features from one of its
+    points, drawn uniformly as a function of (seed, point index); the chosen points are returned as "choice".
 
     offset: cumulative counts, with or without the leading 0 (misc.py:8-13), tensor or list.
     Returns a dict with voxel_coords [N0,4] i32, voxel_feats [N0,C] f32, v2p_map [N] i64,
@@ -102,6 +105,15 @@ def voxelize(coord, feat, offset, grid_size, pad=128, hash_method="fnv", grid_mo
         out["keys"] = keys[:n0]
     if return_grid_coord:
         out["grid_coord"] = gc
+    if pooling_method == "random":
+        choice = torch.empty((n0,), dtype=torch.int64, device=dev)
+        ws2 = _workspace(lib.m3d_voxel_pick_random_workspace_bytes(n0), dev)
+        rc = lib.m3d_voxel_pick_random(_ptr(v2p), _ptr(feat), n, c, n0, int(seed) & (2 ** 64 - 1), _ptr(choice),
+                                       _ptr(voxel_feats), _ptr(ws2), ws2.numel(), _stream())
+        _lib.check(rc, "m3d_voxel_pick_random")
+        out["choice"] = choice
+    elif pooling_method != "mean":
+        raise ValueError(f"Unknown pooling method: {pooling_method}")
     return out
 
 

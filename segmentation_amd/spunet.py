@@ -171,8 +171,11 @@ class BasicBlock(sparse.SparseModule):
 class SpUNet(nn.Module):
     def __init__(self, in_channels=3, out_channels=768, num_classes=0, base_channels=32, context_channels=256,
                  channels=SPUNET34C["channels"], layers=SPUNET34C["layers"], conditions=CONDITIONS,
-                 zero_init=True, norm_decouple=True, norm_adaptive=True, norm_affine=True):
+                 zero_init=True, norm_decouple=True, norm_adaptive=True, norm_affine=True,
+                 hash_method="fnv", pooling_method="mean", pooling_seed=0):
         super().__init__()
+        # voxelizer options of spconv_unet_v1m1_base.SpUNetBase (v1m1:177-178, :335-339); v1m3 always runs the defaults
+        self.hash_method, self.pooling_method, self.pooling_seed = hash_method, pooling_method, pooling_seed
         assert len(layers) % 2 == 0 and len(layers) == len(channels)
         self.in_channels, self.out_channels = in_channels, out_channels
         self.base_channels, self.channels, self.layers = base_channels, tuple(channels), tuple(layers)
@@ -225,8 +228,21 @@ class SpUNet(nn.Module):
                 nn.init.constant_(m.modulation[-1].bias, 0)
 
     def sparsify(self, input_dict, pad=128):
-        vox = ops.voxelize(input_dict["coord"], input_dict["feat"], input_dict["offset"],
-                           input_dict["grid_size"], pad=pad)
+        """Point.sparsify (structure.py:197-251).  A supplied "grid_coord" (GridSample(return_grid_coord=True)) is
+        voxelized as it stands instead of coord / grid_size, and a supplied "sparse_shape" replaces max + pad
+        (structure.py:213-224)."""
+        kw = dict(pad=pad, hash_method=self.hash_method, pooling_method=self.pooling_method, seed=self.pooling_seed)
+        if "grid_coord" in input_dict:
+            gc = input_dict["grid_coord"]
+            if int(gc.min()) != 0 or not bool((gc.min(0)[0] == 0).all()):
+                # the voxelizer shifts by the batch minimum; the reference keeps a supplied grid_coord as it is
+                raise ValueError("grid_coord must start at 0 on every axis (as GridSample produces it)")
+            vox = ops.voxelize(gc.float(), input_dict["feat"], input_dict["offset"], 1.0, **kw)
+        else:
+            vox = ops.voxelize(input_dict["coord"], input_dict["feat"], input_dict["offset"],
+                               input_dict["grid_size"], **kw)
+        if "sparse_shape" in input_dict:
+            vox["spatial_shape"] = [int(v) for v in input_dict["sparse_shape"]]
         x = sparse.SparseConvTensor(vox["voxel_feats"], vox["voxel_coords"], vox["spatial_shape"],
                                     vox["batch_size"])
         return x, vox

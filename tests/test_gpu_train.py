@@ -177,43 +177,7 @@ def test_caption_loss_row_map_equals_gathered_rows(device):
     assert _rel(b.grad, a.grad.cpu()) < 1e-5
 
 
-class _CpuConvs:
-    """Runs a model built on sparse.py's modules on the CPU: voxelisation and every sparse convolution go
-    through the oracle (float64, torch autograd)."""
-
-    def __enter__(self):
-        self._fwd, self._sparsify = sparse.SparseConvolution.forward, spunet.SpUNet.sparsify
-
-        def sparsify(self_, input_dict, pad=128):
-            sp = oracle.sparsify(input_dict["coord"].numpy(), input_dict["feat"].numpy(), np.asarray(input_dict["offset"]),
-                                 input_dict["grid_size"], pad=pad)
-            x = sparse.SparseConvTensor(torch.from_numpy(sp["voxel_feats"]).double(), torch.from_numpy(sp["voxel_coords"]),
-                                        sp["spatial_shape"], sp["batch_size"])
-            return x, dict(v2p_map=torch.from_numpy(sp["v2p_map"]))
-
-        def forward(self_, x):
-            w = self_.weight
-            if self_.conv1x1:
-                return x.replace_feature(oracle.conv1x1(x.features, w, self_.bias))
-            key = ("oracle", self_.indice_key)
-            if self_.inverse:
-                pf, pb, idx, shape = x.indice_dict[key]
-                return sparse.SparseConvTensor(oracle.inverse_conv(x.features, w, pb, self_.bias), idx, shape, x.batch_size,
-                                               indice_dict=x.indice_dict)
-            if self_.subm:
-                if key not in x.indice_dict:
-                    x.indice_dict[key] = oracle.subm_rulebook(x.indices.numpy(), x.spatial_shape)
-                return x.replace_feature(oracle.subm_conv(x.features, w, x.indice_dict[key], self_.bias))
-            oi, oshape, pf, pb = oracle.strided_rulebook(x.indices.numpy(), x.spatial_shape)
-            x.indice_dict[key] = (pf, pb, x.indices, x.spatial_shape)
-            return sparse.SparseConvTensor(oracle.strided_conv(x.features, w, pf, self_.bias), torch.from_numpy(oi), oshape,
-                                           x.batch_size, indice_dict=x.indice_dict)
-
-        sparse.SparseConvolution.forward, spunet.SpUNet.sparsify = forward, sparsify
-        return self
-
-    def __exit__(self, *exc):
-        sparse.SparseConvolution.forward, spunet.SpUNet.sparsify = self._fwd, self._sparsify
+from _refmodel import CpuConvs as _CpuConvs  # noqa: E402  (sparse convolutions through the CPU oracle)
 
 
 def test_whole_training_step_matches_cpu_oracle(device, monkeypatch):

@@ -120,3 +120,50 @@ def test_full_size_properties(device):
     cnt = np.bincount(v2p, minlength=n0)
     vf = out["voxel_feats"].cpu().numpy().astype(np.float64)
     np.testing.assert_allclose((vf * cnt[:, None]).sum(0), sc["feat"].astype(np.float64).sum(0), rtol=1e-5, atol=1e-2)
+
+
+def test_random_pooling(device):
+    """pooling_method="random" (structure.py:69-110): voxel set, order and v2p_map bit-exact (they do not depend on
+    the draw); every voxel's feature is the feature of one of its own points; a seed reproduces the draw, another
+    seed changes it, and over many seeds every point of a voxel gets drawn."""
+    sc = scenes.make_batch([3, 4], target_voxels=3000)
+    sp = oracle.sparsify(sc["coord"], sc["feat"], sc["offset"], 0.02)
+    c, f = torch.from_numpy(sc["coord"]).to(device), torch.from_numpy(sc["feat"]).to(device)
+    outs = [ops.voxelize(c, f, sc["offset"], 0.02, pooling_method="random", seed=s) for s in (7, 7, 8)]
+    for o in outs:
+        assert np.array_equal(o["voxel_coords"].cpu().numpy(), sp["voxel_coords"])
+        assert np.array_equal(o["v2p_map"].cpu().numpy(), sp["v2p_map"])
+        ch = o["choice"].cpu().numpy()
+        assert np.array_equal(sp["v2p_map"][ch], np.arange(sp["voxel_coords"].shape[0]))   # chosen point lies in its voxel
+        assert np.array_equal(o["voxel_feats"].cpu().numpy(), sc["feat"][ch])              # and its feature is copied as is
+    assert torch.equal(outs[0]["choice"], outs[1]["choice"]) and not torch.equal(outs[0]["choice"], outs[2]["choice"])
+    # one voxel with 5 points: 200 seeds draw each of them, roughly uniformly
+    coord = np.full((5, 3), 0.011, dtype=np.float32)
+    feat = np.arange(15, dtype=np.float32).reshape(5, 3)
+    ct, ft = torch.from_numpy(coord).to(device), torch.from_numpy(feat).to(device)
+    hits = np.bincount([int(ops.voxelize(ct, ft, [0, 5], 0.02, pooling_method="random", seed=s)["choice"][0]) for s in range(200)],
+                       minlength=5)
+    assert hits.min() >= 15 and hits.sum() == 200
+    with pytest.raises(ValueError):
+        ops.voxelize(ct, ft, [0, 5], 0.02, pooling_method="max")
+
+
+def test_module_sparsify_options(device):
+    """SpUNet.sparsify honours hash_method / pooling_method (v1m1:177-178) and a supplied grid_coord / sparse_shape
+    (structure.py:213-224)."""
+    from segmentation_amd import spunet
+    sc = scenes.make_batch([5, 6], target_voxels=2000)
+    c, f = torch.from_numpy(sc["coord"]).to(device), torch.from_numpy(sc["feat"]).to(device)
+    net = spunet.SpUNet(channels=(32, 32, 32, 32, 32, 32, 32, 32), layers=(1,) * 8, hash_method="ravel")
+    x, vox = net.sparsify(dict(coord=c, feat=f, offset=sc["offset"], grid_size=0.02))
+    sp = oracle.sparsify(sc["coord"], sc["feat"], sc["offset"], 0.02, hash_method="ravel")
+    assert np.array_equal(x.indices.cpu().numpy(), sp["voxel_coords"]) and x.spatial_shape == list(sp["spatial_shape"])
+    # grid_coord as GridSample would hand it over, with a fixed sparse_shape
+    gc = vox["voxel_coords"][vox["v2p_map"]][:, 1:]
+    net2 = spunet.SpUNet(channels=(32, 32, 32, 32, 32, 32, 32, 32), layers=(1,) * 8)
+    x2, vox2 = net2.sparsify(dict(grid_coord=gc, feat=f, offset=sc["offset"], sparse_shape=[512, 512, 256]))
+    spf = oracle.sparsify(sc["coord"], sc["feat"], sc["offset"], 0.02)
+    assert np.array_equal(x2.indices.cpu().numpy(), spf["voxel_coords"]) and x2.spatial_shape == [512, 512, 256]
+    assert np.array_equal(vox2["v2p_map"].cpu().numpy(), spf["v2p_map"])
+    with pytest.raises(ValueError):
+        net2.sparsify(dict(grid_coord=gc + 1, feat=f, offset=sc["offset"]))

@@ -2,8 +2,6 @@
 their state_dict is key-for-key the one segmentation_amd.spunet exposes (so Mosaic3D checkpoints load).
 Runs only where /root/reference exists (the build container); no forward pass, hence no GPU."""
 import os
-import sys
-import types
 
 import pytest
 import torch
@@ -14,46 +12,9 @@ pytestmark = pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree n
 
 @pytest.fixture(scope="module")
 def reference_modules():
-    from segmentation_amd import compat
-    saved = dict(sys.modules)
-    compat.install(force=True)
-    # packages the reference imports that are not installed here; annotation / container only
-    jt = types.ModuleType("jaxtyping")
-
-    class _Ann:
-        def __class_getitem__(cls, item):
-            return cls
-
-    for n in ("Int", "Float", "Bool"):
-        setattr(jt, n, _Ann)
-    sys.modules["jaxtyping"] = jt
-    ad = types.ModuleType("addict")
-
-    class Dict(dict):
-        __getattr__ = dict.get
-        __setattr__ = dict.__setitem__
-
-    ad.Dict = Dict
-    sys.modules["addict"] = ad
-    timm = types.ModuleType("timm")
-    layers = types.ModuleType("timm.layers")
-    layers.trunc_normal_ = torch.nn.init.trunc_normal_
-    timm.layers = layers
-    sys.modules["timm"], sys.modules["timm.layers"] = timm, layers
-    sys.path.insert(0, REF)
-    old_flag = sys.dont_write_bytecode
-    sys.dont_write_bytecode = True
-    try:
-        from src.models.networks.spunet import spconv_unet_v1m3_pdnorm as v1m3
-        from src.models.networks.ppt import model as ppt
-        from src.models.utils import structure
+    import _refmodel
+    with _refmodel.reference_modules() as (v1m3, v1m1, ppt, structure):
         yield v1m3, ppt, structure
-    finally:
-        sys.dont_write_bytecode = old_flag
-        sys.path.remove(REF)
-        for k in list(sys.modules):
-            if k not in saved:
-                del sys.modules[k]
 
 
 def test_reference_model_builds_on_our_modules_and_shares_the_state_dict(reference_modules):
