@@ -124,32 +124,137 @@ def flatten_caption_indices(batched_indices: Sequence[Sequence[torch.Tensor]], b
     return torch.cat(idx), offsets, counts
 
 
+class GradientReducer:
+    """Data-parallel gradient averaging (configs/trainer/ddp.yaml:4-10: one process per GPU, local batch-norm
+    statistics), bucketed and overlapped with the backward pass.
+
+    The parameters are laid out once, in reverse registration order (roughly the order in which backward finishes
+    them), over flat float32 buckets of about `bucket_bytes`.  Every parameter carries a post-accumulate hook; when
+    the last parameter of a bucket has its gradient, the bucket is packed and its all-reduce is started
+    asynchronously (on RCCL that runs on the communicator's own stream, behind the kernels already enqueued, and
+    overlaps the rest of backward; few, large ring all-reduces suit the point-to-point xGMI links).  finish() starts
+    whatever is left, waits, and writes the averages back.
+
+    Ranks may use different parameters in a step (with decoupled PDBatchNorm only the norms of the batch's own
+    condition receive a gradient, and every rank draws its own dataset): the layout never depends on which gradients
+    exist; a missing gradient contributes zeros, and a parameter receives the averaged gradient iff at least one rank
+    had one (a flag per parameter travels in one small MAX all-reduce) -- otherwise its .grad stays None, as on a
+    single GPU."""
+
+    def __init__(self, params, dist, bucket_bytes: int = 32 << 20, overlap: bool = True):
+        self.dist = dist
+        self.params = [p for p in params if p.requires_grad]
+        self.world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
+        self.overlap = overlap
+        order = list(reversed(range(len(self.params))))
+        self.bucket_of, self.slices, sizes = {}, {}, []
+        size = 0
+        for i in order:
+            n = self.params[i].numel()
+            if not sizes or (size > 0 and (size + n) * 4 > bucket_bytes):
+                sizes.append(0)
+                size = 0
+            bidx = len(sizes) - 1
+            self.bucket_of[i] = bidx
+            self.slices[i] = (size, size + n)
+            size += n
+            sizes[bidx] = size
+        dev = self.params[0].device if self.params else "cpu"
+        self.flat = [torch.zeros(n, dtype=torch.float32, device=dev) for n in sizes]
+        self.members = [[i for i in order if self.bucket_of[i] == b] for b in range(len(sizes))]
+        self.flags = torch.zeros(len(self.params), dtype=torch.float32, device=dev)
+        self._pending = self._works = self._launched = None
+        self._next = 0
+        self._handles = []
+        if self.world > 1 and overlap:
+            for i, p in enumerate(self.params):
+                self._handles.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
+
+    def _make_hook(self, i):
+        def hook(_p):
+            if self._pending is None:   # not between begin() and finish(): gradients are left alone
+                return
+            self._pending[self.bucket_of[i]].discard(i)
+            self._launch_ready()
+        return hook
+
+    def _launch_ready(self):
+        # buckets go out strictly in index order, so that every rank issues the same sequence of collectives
+        # whatever order its gradients arrive in
+        while self._next < len(self.members) and not self._pending[self._next]:
+            self._launch(self._next)
+            self._next += 1
+
+    def begin(self, unused=()):
+        """Call before backward().  `unused`: parameters (objects) known not to receive a gradient in this step on
+        this rank (e.g. the norms of the other dataset conditions): their buckets need not wait for them."""
+        if self.world == 1:
+            return
+        self._pending = [set(m) for m in self.members]
+        if unused:
+            skip = {id(p) for p in unused}
+            for i, p in enumerate(self.params):
+                if id(p) in skip:
+                    self._pending[self.bucket_of[i]].discard(i)
+        self._launched = [False] * len(self.members)
+        self._works = []
+        self._next = 0
+
+    def _launch(self, b):
+        flat = self.flat[b]
+        have = [i for i in self.members[b] if self.params[i].grad is not None]
+        if len(have) != len(self.members[b]):
+            flat.zero_()
+        if have:
+            views = [flat[self.slices[i][0]:self.slices[i][1]].view_as(self.params[i]) for i in have]
+            torch._foreach_copy_(views, [self.params[i].grad for i in have])
+        self._launched[b] = True
+        self._works.append(self.dist.all_reduce(flat, async_op=True))
+
+    def finish(self):
+        """Call after backward(): averaged gradients are in place when it returns.  Returns the bucket count."""
+        if self.world == 1:
+            return 0
+        if self._pending is None:
+            self.begin()
+        for b in range(self._next, len(self.members)):
+            self._launch(b)
+        self._next = len(self.members)
+        self.flags.copy_(torch.tensor([0.0 if p.grad is None else 1.0 for p in self.params]))
+        self.dist.all_reduce(self.flags, op=self.dist.ReduceOp.MAX)
+        for w in self._works:
+            w.wait()
+        used = self.flags.tolist()   # one host read-back per step
+        dst, src = [], []
+        for i, p in enumerate(self.params):
+            if used[i] == 0.0:
+                continue
+            if p.grad is None:
+                p.grad = torch.empty_like(p)
+            lo, hi = self.slices[i]
+            dst.append(p.grad)
+            src.append(self.flat[self.bucket_of[i]][lo:hi].view_as(p))
+        for f in self.flat:
+            f.div_(self.world)
+        if dst:
+            torch._foreach_copy_(dst, src)
+        self._pending = None
+        return len(self.members)
+
+    def close(self):
+        for h in self._handles:
+            h.remove()
+        self._handles = []
+
+
 def allreduce_gradients(params, dist=None, bucket_bytes: int = 64 << 20):
-    """Average the gradients over the data-parallel ranks: parameters are packed into flat buckets (64 MB by
-    default: few, large ring all-reduces suit the point-to-point xGMI links) and all-reduced; no-op without a
-    process group."""
+    """Average the gradients over the data-parallel ranks after backward has finished (no overlap): a
+    GradientReducer used once.  No-op without a process group.  Returns the number of buckets."""
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
         return 0
-    world = dist.get_world_size()
-    grads = [p.grad for p in params if p.grad is not None]
-    buckets, cur, size = [], [], 0
-    for g in grads:
-        cur.append(g)
-        size += g.numel() * g.element_size()
-        if size >= bucket_bytes:
-            buckets.append(cur)
-            cur, size = [], 0
-    if cur:
-        buckets.append(cur)
-    for b in buckets:
-        flat = torch.cat([g.reshape(-1) for g in b])
-        dist.all_reduce(flat)
-        flat /= world
-        o = 0
-        for g in b:
-            g.copy_(flat[o:o + g.numel()].view_as(g))
-            o += g.numel()
-    return len(buckets)
+    red = GradientReducer(list(params), dist, bucket_bytes, overlap=False)
+    red.begin()
+    return red.finish()
 
 
 class TrainStep:
@@ -158,9 +263,13 @@ class TrainStep:
 
     def __init__(self, model: torch.nn.Module, total_steps: int, lr: float = 5e-2, momentum: float = 0.9,
                  weight_decay: float = 1e-4, pct_start: float = 0.05, div_factor: float = 10.0,
-                 final_div_factor: float = 1000.0, dist=None, use_logit_scale: bool = False):
+                 final_div_factor: float = 1000.0, dist=None, use_logit_scale: bool = False, mix_prob: float = 0.0,
+                 seed: int = 0, overlap_allreduce: bool = True):
         self.model = model
         self.dist = dist
+        # language_module.py:212-214: with probability mix_prob neighbouring samples of the batch are merged in pairs
+        self.mix_prob = mix_prob
+        self._rng = np.random.default_rng(seed)
         self.logit_scale = None
         params = list(model.parameters())
         if use_logit_scale:
@@ -171,6 +280,23 @@ class TrainStep:
         self.sched = torch.optim.lr_scheduler.OneCycleLR(self.opt, max_lr=lr, total_steps=total_steps, pct_start=pct_start,
                                                          anneal_strategy="cos", div_factor=div_factor,
                                                          final_div_factor=final_div_factor)
+        self.reducer = None
+        if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+            self.reducer = GradientReducer(self.params, dist, overlap=overlap_allreduce)
+
+    def _idle_params(self, batch):
+        """Parameters of the per-dataset norms of the conditions this batch does not carry (PDBatchNorm picks
+        bns[conditions.index(condition)], spconv_unet_v1m3_pdnorm.py:57-62): they get no gradient in this step."""
+        conditions = getattr(self.model, "conditions", None)
+        cond = batch.get("condition")
+        if not conditions or not cond or cond[0] not in conditions:
+            return ()
+        ci = list(conditions).index(cond[0])
+        cache = self.__dict__.setdefault("_idle_cache", {})
+        if ci not in cache:
+            keep = f".bns.{ci}."
+            cache[ci] = [p for n, p in self.model.named_parameters() if ".bns." in n and keep not in n]
+        return cache[ci]
 
     def loss(self, batch: Dict):
         out = self.model(batch)
@@ -185,9 +311,15 @@ class TrainStep:
     def __call__(self, batch: Dict) -> float:
         self.model.train()
         self.opt.zero_grad(set_to_none=True)
+        if self.mix_prob > 0 and self._rng.random() < self.mix_prob:
+            offset = torch.as_tensor(batch["offset"])
+            batch = dict(batch, offset=torch.cat([offset[1:-1:2], offset[-1:]], dim=0))
         loss = self.loss(batch)
+        if self.reducer is not None:
+            self.reducer.begin(unused=self._idle_params(batch))
         loss.backward()
-        allreduce_gradients(self.params, self.dist)
+        if self.reducer is not None:
+            self.reducer.finish()
         self.opt.step()
         self.sched.step()
         return float(loss.detach())

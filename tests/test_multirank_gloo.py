@@ -92,6 +92,74 @@ def test_gradient_allreduce_two_ranks_gloo():
         assert torch.allclose(m0, (a + b) / 2) and torch.equal(m0, m1)
 
 
+def _uneven_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from segmentation_amd import train
+
+        class Net(torch.nn.Module):
+            """Shared trunk + one head per "condition" (all heads have the same shapes, like the per-dataset norms
+            of PDBatchNorm) + a parameter no rank ever uses."""
+
+            def __init__(self):
+                super().__init__()
+                self.trunk = torch.nn.Linear(6, 8)
+                self.heads = torch.nn.ModuleList([torch.nn.Linear(8, 3) for _ in range(3)])
+                self.unused = torch.nn.Parameter(torch.ones(5))
+
+            def forward(self, x, cond):
+                return self.heads[cond](torch.relu(self.trunk(x)))
+
+        res = {}
+        for overlap in (True, False):
+            torch.manual_seed(0)
+            net = Net()
+            red = train.GradientReducer(list(net.parameters()), dist, bucket_bytes=128, overlap=overlap)
+            for step in range(2):                      # two steps: the layout and the hooks are reused
+                for p in net.parameters():
+                    p.grad = None
+                cond = (rank + step) % 3               # every rank trains another head, and it changes per step
+                x = torch.full((4, 6), float(rank + 1 + step))
+                # the overlapped run is told which heads idle (as TrainStep tells it about the other conditions' norms)
+                red.begin(unused=[p for j in range(3) if j != cond for p in net.heads[j].parameters()] if overlap else ())
+                net(x, cond).square().sum().backward()
+                local = {n: (None if p.grad is None else p.grad.clone()) for n, p in net.named_parameters()}
+                nb = red.finish()
+                res[(overlap, step)] = (nb, cond, local, {n: (None if p.grad is None else p.grad.clone())
+                                                          for n, p in net.named_parameters()})
+            red.close()
+        out[rank] = res
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gradient_allreduce_with_different_parameters_per_rank_gloo():
+    """Ranks whose batches carry different conditions touch different parameters: the averaged gradient of a
+    parameter is sum over the ranks that have one / world, parameters nobody used keep grad None, and the overlapped
+    (hook-driven) exchange gives exactly what the one after backward gives."""
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_uneven_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    for step in range(2):
+        for overlap in (True, False):
+            (nb0, c0, loc0, avg0), (nb1, c1, loc1, avg1) = out[0][(overlap, step)], out[1][(overlap, step)]
+            assert nb0 == nb1 >= 3 and c0 != c1
+            for name in loc0:
+                a, b = loc0[name], loc1[name]
+                if a is None and b is None:
+                    assert avg0[name] is None and avg1[name] is None, name     # used by nobody: untouched
+                    continue
+                want = ((0 if a is None else a) + (0 if b is None else b)) / world
+                assert torch.allclose(avg0[name], want) and torch.equal(avg0[name], avg1[name]), name
+            assert avg0["unused"] is None and avg0[f"heads.{c0}.weight"] is not None and avg0[f"heads.{c1}.weight"] is not None
+        for name in out[0][(True, step)][3]:
+            x, y = out[0][(True, step)][3][name], out[0][(False, step)][3][name]
+            assert (x is None and y is None) or torch.equal(x, y), name
+
+
 def test_bench_starts_its_own_ranks_dry_run():
     """`python bench.py --gpus 2` outside a launcher starts two ranks itself (before anything touches a GPU) and
     relays rank 0's JSON line; --dry-run rehearses sharding and the job reduction over gloo without kernels."""
