@@ -62,6 +62,11 @@ class SpUNetEngine:
                  precision: str = "f32"):
         """model_or_state: a PPT module (segmentation_amd.spunet.PPT or the reference's) or its state_dict
         ('backbone.*' + 'embedding_table.weight').  cfg: channels / layers / conditions of the backbone."""
+        self.device = torch.device(device)
+        with torch.cuda.device(self.device):
+            self._init(model_or_state, cfg, condition, precision)
+
+    def _init(self, model_or_state, cfg, condition, precision):
         sd = model_or_state.state_dict() if hasattr(model_or_state, "state_dict") else dict(model_or_state)
         sd = {k: v.detach().to("cpu") for k, v in sd.items()}
         self.cfg = cfg
@@ -80,7 +85,6 @@ class SpUNetEngine:
         self.fuse_head = os.environ.get("M3D_FUSE_HEAD", "1") != "0"
         # 128-row tiles of the submanifold convolutions are launched heaviest first (m3d_schedule_tile_order)
         self.tile_order = os.environ.get("M3D_TILE_ORDER", "1") != "0"
-        self.device = torch.device(device)
         self.channels, self.layers = tuple(cfg["channels"]), tuple(cfg["layers"])
         self.num_stages = len(self.layers) // 2
         self.condition = condition
@@ -120,6 +124,10 @@ class SpUNetEngine:
     # ------------------------------------------------------------------ head
     def set_text_embeddings(self, emb: torch.Tensor):
         """emb [C, D] (rows are unit-norm CLIP text features, clip_alignment_loss.py:123-124)."""
+        with torch.cuda.device(self.device):
+            self._set_text_embeddings(emb)
+
+    def _set_text_embeddings(self, emb: torch.Tensor):
         emb = emb.detach().float().to(self.device)
         c, d = emb.shape
         if d != self.final.cout:
@@ -257,6 +265,10 @@ class SpUNetEngine:
     def forward_features(self, coord, feat, offset, grid_size, keep=None, want_split=False, want_f32=True):
         """Whole path up to the per-voxel open-vocabulary features.  Returns (features [N0, D], vox dict); with
         want_split the first member is the pair (f32 features or None, split features)."""
+        with torch.cuda.device(self.device):   # kernels launch on the current device's stream
+            return self._forward_features(coord, feat, offset, grid_size, keep, want_split, want_f32)
+
+    def _forward_features(self, coord, feat, offset, grid_size, keep=None, want_split=False, want_f32=True):
         vox, levels = self._voxelize_and_maps(coord, feat, offset, grid_size)
         x = self.backbone(vox["voxel_feats"], levels, keep)
         out_pair = self._conv(self.final, x, None, levels[0].n, need_f32=want_f32 or not want_split, need_sf=want_split)
@@ -271,9 +283,16 @@ class SpUNetEngine:
 
     @torch.no_grad()
     def predict(self, coord, feat, offset, grid_size, fold_head=False, return_logits=False):
-        """Per-point labels (int64), like logits.max(1)[1] on clip_feat @ emb_target.T."""
+        """Per-point labels (int64), like logits.max(1)[1] on clip_feat @ emb_target.T.  return_logits adds the
+        per-voxel logits of the features as they are (CLIPAlignmentEval with normalize_input=False, as
+        configs/model/loss/caption.yaml:7 sets it; normalising the rows first scales every row of logits by a
+        positive number and leaves the labels unchanged)."""
         if self.text is None:
             raise RuntimeError("call set_text_embeddings() first")
+        with torch.cuda.device(self.device):
+            return self._predict(coord, feat, offset, grid_size, fold_head, return_logits)
+
+    def _predict(self, coord, feat, offset, grid_size, fold_head, return_logits):
         vlabel = None
         if self.text_fused is not None and not fold_head:
             # `final`, the logits and the argmax in one kernel: the CLIP features stay on chip
@@ -291,8 +310,8 @@ class SpUNetEngine:
             self.last_stats = dict(n_points=int(coord.shape[0]), n_voxels=[levels[l].n for l in range(len(levels))])
         else:
             # the head consumes the split features directly; the f32 copy is only written when asked for
-            pair, vox = self.forward_features(coord, feat, offset, grid_size, want_split=self._terms != 0,
-                                              want_f32=False)
+            pair, vox = self._forward_features(coord, feat, offset, grid_size, want_split=self._terms != 0,
+                                               want_f32=False)
             src = pair[1] if self._terms else pair
             logits = ops.conv_fwd(src, self.text.w, None, self.last_stats["n_voxels"][0], flop_cout=self.n_classes)
         if vlabel is None:

@@ -40,10 +40,17 @@ def _workspace(nbytes: int, device) -> torch.Tensor:
 
 
 def _need_cuda(*ts):
+    """Every operator launches on the current stream of the CURRENT device: tensors must live there."""
     for t in ts:
-        if t is not None and not t.is_cuda:
+        if t is None:
+            continue
+        if not t.is_cuda:
             raise RuntimeError("segmentation_amd operators need tensors on an AMD GPU (cuda device); "
                                "there is no CPU path")
+        if t.device.index != torch.cuda.current_device():
+            raise RuntimeError(f"tensor on {t.device} but the current device is cuda:{torch.cuda.current_device()}: "
+                               "run under `with torch.cuda.device(tensor.device):` (one process per GPU is the "
+                               "intended deployment)")
 
 
 def _shape3(shape: Sequence[int]):

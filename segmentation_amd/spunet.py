@@ -288,7 +288,16 @@ class SpUNet(nn.Module):
         x, vox = self.sparsify(input_dict)
         condition = input_dict["condition"][0]
         context = input_dict.get("context")
-        self._fold_modulations(condition, context, x.features.dtype)
+        try:
+            self._fold_modulations(condition, context, x.features.dtype)
+            return self._forward_net(x, vox, condition, context)
+        finally:
+            # the folded affine pairs are for this call only: a forward that raised half-way must not leave any
+            # behind for the next call (or for a direct call of a sub-module)
+            for m in self.__dict__.get("_pd_norms") or ():
+                m.__dict__.pop("_affine", None)
+
+    def _forward_net(self, x, vox, condition, context):
         x = self.conv_input([x, condition, context])
         if context is not None:
             context = context.to(x.features.dtype)
