@@ -139,9 +139,12 @@ int m3d_backproject(const uint16_t* d_depth, const uint8_t* d_conf, const uint8_
  *   d_indices [n,4] i32 (batch, d0, d1, d2), rows distinct
  *   d_pair    [27,n] i32  pair[k][j] = i with indices[i] == indices[j] + offset(k), else -1;
  *                          k = (k0*3 + k1)*3 + k2, offset = (k0-1, k1-1, k2-1)
+ *   batch_size: SparseConvTensor.batch_size (every batch index < batch_size), or 0 if unknown.  With a known batch
+ *               size and batch_size * volume <= 2^28 cells the neighbours are found through an occupancy bitmap of
+ *               the grid (bit rank = voxel number); otherwise through an open-addressing hash table of 64-bit keys.
  */
-size_t m3d_subm_rulebook_workspace_bytes(int64_t n);
-int m3d_subm_rulebook(const int32_t* d_indices, int64_t n, const int64_t spatial_shape[3],
+size_t m3d_subm_rulebook_workspace_bytes(int64_t n, const int64_t spatial_shape[3], int batch_size);
+int m3d_subm_rulebook(const int32_t* d_indices, int64_t n, const int64_t spatial_shape[3], int batch_size,
                       int32_t* d_pair, void* d_ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
@@ -293,6 +296,26 @@ int m3d_bn_stats(const float* d_x, int64_t n, int c, float* d_mean, float* d_var
 int m3d_bn_backward_reduce(const float* d_x, const float* d_dy, const float* d_mean, int64_t n, int c,
                            float* d_sum_dy, float* d_sum_dy_xmu, void* d_ws, size_t ws_bytes, void* stream);
 
+/* Training-mode normalisation fused with what follows it in BasicBlock.forward / SPConvDown / SPConvUp
+ * (spconv_unet_v1m3_pdnorm.py:121-140, :143-199): y = act(bn(x) + residual), one pass forward and two backward
+ * instead of separate normalise, add and ReLU passes.  Statistics come from m3d_bn_stats (d_var = biased variance).
+ *   m3d_bn_act_fwd:             y = relu?((x - mean) * rsqrt(var + eps) * weight + bias + residual)
+ *                               (d_weight / d_bias / d_residual may be NULL = 1 / 0 / none)
+ *   m3d_bn_act_backward_reduce: g = dy where y > 0 (d_y = the forward output; NULL = no ReLU, g = dy);
+ *                               d_sum_g[c] = sum_r g, d_sum_g_xmu[c] = sum_r g * (x - mean); float64 sums, fixed
+ *                               order, workspace m3d_bn_workspace_bytes(n, c)
+ *   m3d_bn_act_backward:        dx = (g - sum_g/n - (x - mean) * sum_g_xmu/n / (var + eps)) * rsqrt(var + eps) * weight;
+ *                               d_dres (may be NULL) = g, the gradient of the residual input
+ *   (the parameter gradients are d_sum_g_xmu * rsqrt(var + eps) and d_sum_g).  c a multiple of 4, 16-byte aligned. */
+int m3d_bn_act_fwd(const float* d_x, int64_t n, int c, const float* d_mean, const float* d_var, float eps,
+                   const float* d_weight, const float* d_bias, const float* d_residual, int relu, float* d_y,
+                   void* stream);
+int m3d_bn_act_backward_reduce(const float* d_x, const float* d_dy, const float* d_y, const float* d_mean, int64_t n,
+                               int c, float* d_sum_g, float* d_sum_g_xmu, void* d_ws, size_t ws_bytes, void* stream);
+int m3d_bn_act_backward(const float* d_x, const float* d_dy, const float* d_y, int64_t n, int c, const float* d_mean,
+                        const float* d_var, float eps, const float* d_weight, const float* d_sum_g,
+                        const float* d_sum_g_xmu, float* d_dx, float* d_dres, void* stream);
+
 /* m3d_bn_stats without any allocation and without a workspace argument: the per-workgroup partial sums live in a
  * fixed 4 MiB array inside the library's code object (every GPU the library runs on holds its own copy until the
  * process ends).  Has no counterpart in the reference; it is for callers that cannot allocate device memory: code
@@ -380,6 +403,17 @@ int m3d_head_fused_sf32(const void* d_in_split, int cin, int64_t n, const void* 
  */
 int m3d_avgpool_fwd(const float* d_in, int c, const int32_t* d_pair, int k, int64_t ld, int64_t n_out,
                     float* d_out, int32_t* d_count, void* stream);
+
+/* The fused head for `terms` = 2 (the entry points above) or 3 (M3D_PREC_BF16X6 products, leading and small
+ * products accumulated separately): d_in_split, d_w1 (m3d_conv_pack_weight with M3D_PREC_BF16X6) and the packed text
+ * are in the split format of that term count ([..][C/16][3][16] bf16 for three terms).  Same shapes supported, same
+ * outputs, same reference call sites as m3d_head_fused_sf32. */
+size_t m3d_head_text_bytes_terms(int classes_padded, int cmid, int terms);
+int m3d_head_pack_text_terms(const float* d_text, int n_classes, int cmid, int classes_padded, int terms, void* d_out,
+                             void* stream);
+int m3d_head_fused_terms(const void* d_in_split, int cin, int64_t n, int terms, const void* d_w1, const float* d_scale,
+                         const float* d_shift, int cmid, const void* d_text_packed, int classes_padded, int n_classes,
+                         float* d_logits, int64_t ldl, int32_t* d_voxel_label, void* stream);
 
 #ifdef __cplusplus
 }

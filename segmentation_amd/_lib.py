@@ -32,8 +32,8 @@ SIGNATURES = {
     "m3d_backproject": (_int, [_vp, _vp, _vp, _int, _int, _int, _int, ctypes.POINTER(ctypes.c_double),
                                ctypes.POINTER(ctypes.c_double), ctypes.c_double, ctypes.c_double, _int, _int, _vp, _vp,
                                _i64, _vp, _vp, _sz, _vp]),
-    "m3d_subm_rulebook_workspace_bytes": (_sz, [_i64]),
-    "m3d_subm_rulebook": (_int, [_vp, _i64, ctypes.POINTER(_i64), _vp, _vp, _sz, _vp]),
+    "m3d_subm_rulebook_workspace_bytes": (_sz, [_i64, ctypes.POINTER(_i64), _int]),
+    "m3d_subm_rulebook": (_int, [_vp, _i64, ctypes.POINTER(_i64), _int, _vp, _vp, _sz, _vp]),
     "m3d_strided_rulebook_workspace_bytes": (_sz, [_i64, ctypes.POINTER(_i64), _int]),
     "m3d_strided_rulebook": (_int, [_vp, _i64, _vp, ctypes.POINTER(_i64), _int, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "m3d_schedule_npad": (_i64, [_i64]),
@@ -51,6 +51,9 @@ SIGNATURES = {
     "m3d_conv_bwd_weight_bf16x3": (_int, [_vp, _int, _vp, _int, _int, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _sz, _vp]),
     "m3d_bn_workspace_bytes": (_sz, [_i64, _int]),
     "m3d_bn_stats": (_int, [_vp, _i64, _int, _vp, _vp, _vp, _sz, _vp]),
+    "m3d_bn_act_fwd": (_int, [_vp, _i64, _int, _vp, _vp, _f32, _vp, _vp, _vp, _int, _vp, _vp]),
+    "m3d_bn_act_backward_reduce": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _vp, _vp, _vp, _sz, _vp]),
+    "m3d_bn_act_backward": (_int, [_vp, _vp, _vp, _i64, _int, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "m3d_bn_stats_static_max_bytes": (_sz, []),
     "m3d_bn_stats_static": (_int, [_vp, _i64, _int, _vp, _vp, _vp]),
     "m3d_bn_backward_reduce": (_int, [_vp, _vp, _vp, _i64, _int, _vp, _vp, _vp, _sz, _vp]),
@@ -67,6 +70,9 @@ SIGNATURES = {
     "m3d_avgpool_fwd": (_int, [_vp, _int, _vp, _int, _i64, _i64, _vp, _vp, _vp]),
     "m3d_head_text_bytes": (_sz, [_int, _int]),
     "m3d_head_pack_text": (_int, [_vp, _int, _int, _int, _vp, _vp]),
+    "m3d_head_text_bytes_terms": (_sz, [_int, _int, _int]),
+    "m3d_head_pack_text_terms": (_int, [_vp, _int, _int, _int, _int, _vp, _vp]),
+    "m3d_head_fused_terms": (_int, [_vp, _int, _i64, _int, _vp, _vp, _vp, _int, _vp, _int, _int, _vp, _i64, _vp, _vp]),
     "m3d_head_fused_sf32": (_int, [_vp, _int, _i64, _vp, _vp, _vp, _int, _vp, _int, _int, _vp, _i64, _vp, _vp]),
 }
 

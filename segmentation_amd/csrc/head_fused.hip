@@ -354,13 +354,255 @@ static int launch_head(const HeadArgs& a, hipStream_t stream) {
   return M3D_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// The same head for three-term operands (M3D_PREC_BF16X6: f32-level products).  Activations, W1 and the text matrix
+// arrive in the three-term split format with 16-channel groups ([..][C/16][3][16] bf16), so a stage of 32 features
+// is, per feature, G1 = cin/16 rows of 96 bytes of W1 and, per class, two rows of 96 bytes of the text matrix; LDS
+// rows are 96 bytes with the pair swizzle of DmaGeom<3>.  Four waves x 32 voxel rows per workgroup, one wave per
+// SIMD (activation fragments, logits accumulators and operand terms need about 260 registers), two LDS buffers, one
+// barrier per stage: the DMA of stage s + 1 is requested right after the barrier that publishes stage s.  The
+// features accumulate leading and small products separately, as the convolution kernel does; the logits, which only
+// feed the argmax, use one accumulator per class tile.
+template <int G1, int NT2>
+__device__ __forceinline__ void head_fused3_body(const HeadArgs& a) {
+  using G = DmaGeom<3>;
+  constexpr int NTHR = 256, ROWS = 128;
+  constexpr int W1_ROWS = 32 * G1, W2_ROWS = 2 * NT2 * 32;
+  constexpr int W1_BYTES = W1_ROWS * G::ROWB, BUF = (W1_ROWS + W2_ROWS) * G::ROWB;
+  constexpr int W1_SLOTS = W1_ROWS * G::SLOTS, SLOTS = W1_SLOTS + W2_ROWS * G::SLOTS;
+  constexpr int GI = (SLOTS + NTHR - 1) / NTHR;
+  static_assert(W1_BYTES % 256 == 0 && BUF % 256 == 0, "images start on a bank line");
+  extern __shared__ __align__(16) char ldsb[];
+  float* aff_s = reinterpret_cast<float*>(ldsb + 2 * BUF);  // [2][kHeadMaxFeatures]: scale, shift
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r32 = lane & 31, h = lane >> 5;
+  const int64_t tile_base = (int64_t)blockIdx.x * ROWS;
+  const int nstage = a.cmid >> 5;
+  const int ngrp = a.cmid >> 4;  // 16-feature groups of the text matrix
+  const uint32_t lds_base = (uint32_t)(uintptr_t)(lds_ptr_t)ldsb;
+
+  // activation fragments of this wave's 32 rows: [channel group][term], 8 channels per lane
+  bf16x8 xf[G1][3];
+  {
+    const int64_t row = tile_base + wave * 32 + r32;
+    const char* xp = a.x + (row < a.n ? row : a.n) * (int64_t)(G1 * 96);
+#pragma unroll
+    for (int g = 0; g < G1; ++g)
+#pragma unroll
+      for (int t = 0; t < 3; ++t) xf[g][t] = *reinterpret_cast<const bf16x8*>(xp + g * 96 + t * 32 + h * 16);
+  }
+  for (int i = tid; i < a.cmid; i += NTHR) {
+    aff_s[i] = a.scale ? a.scale[i] : 1.f;
+    aff_s[kHeadMaxFeatures + i] = a.shift ? a.shift[i] : 0.f;
+  }
+
+  // DMA addressing (loop invariant): slot e = v * NTHR + tid of a buffer is (image row e / 6, physical slot e % 6)
+  // and carries logical piece (e % 6) ^ swz(row).  W1 image rows: group * 32 + feature; text image rows:
+  // (k-step * NT2 + class tile) * 32 + class.
+  const char* src0[GI];
+  uint32_t step[GI];
+  bool on[GI];
+#pragma unroll
+  for (int v = 0; v < GI; ++v) {
+    const int e = v * NTHR + tid;
+    on[v] = e < SLOTS;
+    if (e < W1_SLOTS) {
+      const int rr = e / G::SLOTS, g = rr >> 5, m = rr & 31;
+      const int p = (e % G::SLOTS) ^ G::swz(rr);
+      src0[v] = a.w1 + ((m * G1 + g) * 96 + p * 16);
+      step[v] = 32 * G1 * 96;
+    } else {
+      const int e2 = (e < SLOTS ? e : W1_SLOTS) - W1_SLOTS, rr = e2 / G::SLOTS;
+      const int ks = rr / (NT2 * 32), j = rr % (NT2 * 32);
+      const int p = (e2 % G::SLOTS) ^ G::swz(rr);
+      src0[v] = a.w2 + (((int64_t)j * ngrp + ks) * 96 + p * 16);
+      step[v] = 2 * 96;
+    }
+  }
+  auto issue = [&](int s, int bi) {
+    char* buf = ldsb + bi * BUF;
+#pragma unroll
+    for (int v = 0; v < GI; ++v)
+      if (v * NTHR + wave * 64 < SLOTS) {  // wave-uniform
+        if (on[v])
+          __builtin_amdgcn_global_load_lds(src0[v] + (uint32_t)s * step[v], (lds_ptr_t)(buf + (v * NTHR + wave * 64) * 16),
+                                           16, 0, 0);
+      }
+  };
+
+  // fragment read offsets inside an image: piece 2 t + h of row (.. + r32); the swizzle depends on r32 only because
+  // every image row base is a multiple of 32 rows
+  uint32_t frag[3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t) frag[t] = r32 * G::ROWB + (((2 * t + h) ^ G::swz(r32)) * 16);
+
+  floatx16 acc[NT2];
+#pragma unroll
+  for (int i = 0; i < NT2; ++i)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
+
+  issue(0, 0);
+  for (int s = 0; s < nstage; ++s) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // stage s has landed for every wave; every wave is done with stage s - 1
+    asm volatile("" ::: "memory");
+    if (s + 1 < nstage) issue(s + 1, (s + 1) & 1);
+
+    // A: F^T tile (features x rows) = W1 tile . X^T, six products per channel group.  The three fragment reads of a
+    // step are issued by hand (lds_read16) one step ahead of the products that consume them and waited for with a
+    // counted lgkmcnt: LDS reads return in order, so "at most 3 outstanding" after requesting step g + 1 means that
+    // step g has arrived.
+    const uint32_t sb = lds_base + (uint32_t)((s & 1) * BUF);
+    const uint32_t p0 = sb + frag[0], p1 = sb + frag[1], p2 = sb + frag[2];
+    floatx16 fh, fl;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) fh[j] = fl[j] = 0.f;
+    {
+      bf16x8 w[2][3];
+      lds_read16<0>(w[0][0], p0);
+      lds_read16<0>(w[0][1], p1);
+      lds_read16<0>(w[0][2], p2);
+      static_for<0, G1>([&](auto gc) {
+        constexpr int g = decltype(gc)::value;
+        if constexpr (g + 1 < G1) {
+          lds_read16<(g + 1) * 32 * G::ROWB>(w[(g + 1) & 1][0], p0);
+          lds_read16<(g + 1) * 32 * G::ROWB>(w[(g + 1) & 1][1], p1);
+          lds_read16<(g + 1) * 32 * G::ROWB>(w[(g + 1) & 1][2], p2);
+          asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(w[g & 1][0]), "+v"(w[g & 1][1]), "+v"(w[g & 1][2]));
+        } else {
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(w[g & 1][0]), "+v"(w[g & 1][1]), "+v"(w[g & 1][2]));
+        }
+        fl = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[g & 1][0], xf[g][2], fl, 0, 0, 0);
+        fl = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[g & 1][2], xf[g][0], fl, 0, 0, 0);
+        fl = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[g & 1][1], xf[g][1], fl, 0, 0, 0);
+        fl = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[g & 1][0], xf[g][1], fl, 0, 0, 0);
+        fl = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[g & 1][1], xf[g][0], fl, 0, 0, 0);
+        fh = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[g & 1][0], xf[g][0], fh, 0, 0, 0);
+      });
+    }
+    // register j holds feature (j & 3) + 8 * (j >> 2) + 4 * h of the tile: affine, then three bf16 terms per k-step
+    bf16x8 at[2][3];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int ft = s * 32 + (j & 3) + 8 * (j >> 2) + 4 * h;
+      float v = (fh[j] + fl[j]) * aff_s[ft] + aff_s[kHeadMaxFeatures + ft];
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        const __bf16 q = (__bf16)v;
+        at[j >> 3][t][j & 7] = q;
+        v -= (float)q;
+      }
+    }
+    // B: logits += F tile . text tile (one accumulator per class tile: the logits only feed the argmax); same
+    // hand-issued fragment pipeline.  Step i = k-step * NT2 + class tile: consecutive steps read consecutive rows.
+    {
+      bf16x8 bq[2][3];
+      const uint32_t q0 = p0 + W1_BYTES, q1 = p1 + W1_BYTES, q2 = p2 + W1_BYTES;
+      lds_read16<0>(bq[0][0], q0);
+      lds_read16<0>(bq[0][1], q1);
+      lds_read16<0>(bq[0][2], q2);
+      static_for<0, 2 * NT2>([&](auto ic) {
+        constexpr int i = decltype(ic)::value, ks = i / NT2, nt = i % NT2;
+        if constexpr (i + 1 < 2 * NT2) {
+          lds_read16<(i + 1) * 32 * G::ROWB>(bq[(i + 1) & 1][0], q0);
+          lds_read16<(i + 1) * 32 * G::ROWB>(bq[(i + 1) & 1][1], q1);
+          lds_read16<(i + 1) * 32 * G::ROWB>(bq[(i + 1) & 1][2], q2);
+          asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(bq[i & 1][0]), "+v"(bq[i & 1][1]), "+v"(bq[i & 1][2]));
+        } else {
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bq[i & 1][0]), "+v"(bq[i & 1][1]), "+v"(bq[i & 1][2]));
+        }
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[ks][0], bq[i & 1][2], acc[nt], 0, 0, 0);
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[ks][2], bq[i & 1][0], acc[nt], 0, 0, 0);
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[ks][1], bq[i & 1][1], acc[nt], 0, 0, 0);
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[ks][0], bq[i & 1][1], acc[nt], 0, 0, 0);
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[ks][1], bq[i & 1][0], acc[nt], 0, 0, 0);
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[ks][0], bq[i & 1][0], acc[nt], 0, 0, 0);
+      });
+    }
+  }
+
+  // epilogue: accumulator register r is row (r & 3) + 8 * (r >> 2) + 4 * h, class nt * 32 + r32
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int64_t row = tile_base + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+    const bool live = row < a.n;
+    float best = 0.f;
+    int bi = 0x7FFFFFFF;
+#pragma unroll
+    for (int nt = 0; nt < NT2; ++nt) {
+      const int c = nt * 32 + r32;
+      const float v = acc[nt][r];
+      if (a.logits && live && c < a.ldl) a.logits[row * a.ldl + c] = v;
+      // first index of the maximum: the first real class is taken as is, later ones only when strictly greater
+      if (c < a.n_classes && (bi == 0x7FFFFFFF || v > best)) {
+        best = v;
+        bi = c;
+      }
+    }
+    if (a.label) {
+#pragma unroll
+      for (int sft = 1; sft < 32; sft <<= 1) {
+        const float ov = __shfl_xor(best, sft);
+        const int oi = __shfl_xor(bi, sft);
+        if (oi != 0x7FFFFFFF && (bi == 0x7FFFFFFF || ov > best || (ov == best && oi < bi))) {
+          best = ov;
+          bi = oi;
+        }
+      }
+      if (live && r32 == 0) a.label[row] = bi;
+    }
+  }
+}
+
+template <int G1, int NT2>
+__global__ __launch_bounds__(256) void head_fused3_kernel(HeadArgs a) {
+  head_fused3_body<G1, NT2>(a);
+}
+
+template <int G1, int NT2>
+static int launch_head3(const HeadArgs& a, hipStream_t stream) {
+  constexpr size_t BUF = (size_t)(32 * G1 + 2 * NT2 * 32) * DmaGeom<3>::ROWB;
+  constexpr size_t lds = 2 * BUF + 2 * kHeadMaxFeatures * sizeof(float);
+  static_assert(lds <= 160 * 1024, "LDS budget");
+  static LdsGrant grant;
+  if (int rc = grant.ensure(reinterpret_cast<const void*>(&head_fused3_kernel<G1, NT2>), lds)) return rc;
+  hipLaunchKernelGGL((head_fused3_kernel<G1, NT2>), dim3((unsigned)cdiv(a.n, 128)), dim3(256), lds, stream, a);
+  M3D_LAUNCH_CHECK();
+  return M3D_OK;
+}
+
+// text [n_classes][cmid] f32 -> [classes_padded][cmid/16][3][16] bf16, features permuted inside each group of 32
+// exactly as in the two-term packing (rows >= n_classes zero)
+__global__ void head_pack_text3_kernel(const float* __restrict__ text, int n_classes, int cmid, int classes_padded,
+                                       __bf16* __restrict__ out) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (int64_t)classes_padded * cmid) return;
+  const int j = (int)(e / cmid), q = (int)(e % cmid);
+  float v = j < n_classes ? text[(int64_t)j * cmid + (q & ~31) + head_perm_channel(q & 31)] : 0.f;
+  __bf16* dst = out + (((int64_t)j * (cmid >> 4) + (q >> 4)) * 3) * 16 + (q & 15);
+  for (int t = 0; t < 3; ++t) {
+    const __bf16 b = (__bf16)v;
+    dst[t * 16] = b;
+    v -= (float)b;
+  }
+}
+
 }  // namespace m3d
 
 using namespace m3d;
 
+extern "C" size_t m3d_head_text_bytes_terms(int classes_padded, int cmid, int terms) {
+  if (classes_padded <= 0 || cmid <= 0 || (terms != 2 && terms != 3)) return 0;
+  return (size_t)classes_padded * cmid * terms * sizeof(__bf16);
+}
+
 extern "C" size_t m3d_head_text_bytes(int classes_padded, int cmid) {
-  if (classes_padded <= 0 || cmid <= 0) return 0;
-  return (size_t)classes_padded * cmid * 2 * sizeof(__bf16);
+  return m3d_head_text_bytes_terms(classes_padded, cmid, 2);
 }
 
 extern "C" int m3d_head_pack_text(const float* d_text, int n_classes, int cmid, int classes_padded, void* d_out,
@@ -371,6 +613,21 @@ extern "C" int m3d_head_pack_text(const float* d_text, int n_classes, int cmid, 
                 "m3d_head_pack_text: bad sizes");
   const int64_t total = (int64_t)classes_padded * cmid;
   hipLaunchKernelGGL(head_pack_text_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, stream, d_text, n_classes,
+                     cmid, classes_padded, static_cast<__bf16*>(d_out));
+  M3D_LAUNCH_CHECK();
+  return M3D_OK;
+}
+
+extern "C" int m3d_head_pack_text_terms(const float* d_text, int n_classes, int cmid, int classes_padded, int terms,
+                                        void* d_out, void* stream_) {
+  if (terms == 2) return m3d_head_pack_text(d_text, n_classes, cmid, classes_padded, d_out, stream_);
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  M3D_CHECK_ARG(terms == 3, "m3d_head_pack_text_terms: terms must be 2 or 3");
+  M3D_CHECK_ARG(d_text && d_out, "m3d_head_pack_text_terms: null pointer");
+  M3D_CHECK_ARG(n_classes >= 1 && n_classes <= classes_padded && classes_padded % 32 == 0 && cmid >= 32 && cmid % 32 == 0,
+                "m3d_head_pack_text_terms: bad sizes");
+  const int64_t total = (int64_t)classes_padded * cmid;
+  hipLaunchKernelGGL(head_pack_text3_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, stream, d_text, n_classes,
                      cmid, classes_padded, static_cast<__bf16*>(d_out));
   M3D_LAUNCH_CHECK();
   return M3D_OK;
@@ -413,5 +670,46 @@ extern "C" int m3d_head_fused_sf32(const void* d_in_split, int cin, int64_t n, c
 #undef M3D_HEAD_CASE
   set_error("m3d_head_fused_sf32: no kernel for %d input channels and %d padded classes (supported: 96 channels "
             "with 32..256 classes in steps of 32; 32/64/128 channels with 128 or 256 classes)", cin, classes_padded);
+  return M3D_EINVAL;
+}
+
+extern "C" int m3d_head_fused_terms(const void* d_in_split, int cin, int64_t n, int terms, const void* d_w1,
+                                    const float* d_scale, const float* d_shift, int cmid, const void* d_text_packed,
+                                    int classes_padded, int n_classes, float* d_logits, int64_t ldl,
+                                    int32_t* d_voxel_label, void* stream_) {
+  if (terms == 2)
+    return m3d_head_fused_sf32(d_in_split, cin, n, d_w1, d_scale, d_shift, cmid, d_text_packed, classes_padded, n_classes,
+                               d_logits, ldl, d_voxel_label, stream_);
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  const char* who = "m3d_head_fused_terms";
+  M3D_CHECK_ARG(terms == 3, "%s: terms must be 2 or 3", who);
+  if (n == 0) return M3D_OK;
+  M3D_CHECK_ARG(d_in_split && d_w1 && d_text_packed, "%s: null pointer", who);
+  M3D_CHECK_ARG(d_logits || d_voxel_label, "%s: no output requested", who);
+  M3D_CHECK_ARG(n > 0 && cmid >= 32 && cmid % 32 == 0 && cmid <= kHeadMaxFeatures && n_classes >= 1 &&
+                    n_classes <= classes_padded,
+                "%s: bad sizes", who);
+  M3D_CHECK_ARG(d_logits == nullptr || ldl >= n_classes, "%s: logits rows shorter than n_classes", who);
+  HeadArgs a = {};
+  a.x = static_cast<const char*>(d_in_split);
+  a.w1 = static_cast<const char*>(d_w1);
+  a.w2 = static_cast<const char*>(d_text_packed);
+  a.scale = d_scale;
+  a.shift = d_shift;
+  a.logits = d_logits;
+  a.ldl = ldl;
+  a.label = d_voxel_label;
+  a.n = n;
+  a.cmid = cmid;
+  a.n_classes = n_classes;
+#define M3D_HEAD3_CASE(CIN_, CP_) \
+  if (cin == CIN_ && classes_padded == CP_) return launch_head3<CIN_ / 16, CP_ / 32>(a, stream);
+  M3D_HEAD3_CASE(96, 32) M3D_HEAD3_CASE(96, 64) M3D_HEAD3_CASE(96, 96) M3D_HEAD3_CASE(96, 128) M3D_HEAD3_CASE(96, 160)
+  M3D_HEAD3_CASE(96, 192) M3D_HEAD3_CASE(96, 224) M3D_HEAD3_CASE(96, 256)
+  M3D_HEAD3_CASE(32, 128) M3D_HEAD3_CASE(32, 256) M3D_HEAD3_CASE(64, 128) M3D_HEAD3_CASE(64, 256)
+  M3D_HEAD3_CASE(128, 128) M3D_HEAD3_CASE(128, 256)
+#undef M3D_HEAD3_CASE
+  set_error("%s: no three-term kernel for %d input channels and %d padded classes (supported: 96 channels with 32..256 "
+            "classes in steps of 32; 32/64/128 channels with 128 or 256 classes)", who, cin, classes_padded);
   return M3D_EINVAL;
 }

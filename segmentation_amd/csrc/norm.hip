@@ -29,10 +29,12 @@ static __device__ __align__(256) double scratch[kStaticScratchBytes / sizeof(dou
 template <int NQ>
 __global__ __launch_bounds__(kNormThreads) void norm_partial_kernel(const float* __restrict__ x,
                                                                     const float* __restrict__ dy,
-                                                                    const float* __restrict__ mean, int64_t n, int c,
+                                                                    const float* __restrict__ mean,
+                                                                    const float* __restrict__ ymask, int64_t n, int c,
                                                                     int64_t rows_per_block,
                                                                     double* __restrict__ partial) {
-  // NQ = 2 quantities per channel: (sum x, sum x^2) when dy == nullptr, else (sum dy, sum dy*(x - mean))
+  // NQ = 2 quantities per channel: (sum x, sum x^2) when dy == nullptr, else (sum g, sum g*(x - mean)) with
+  // g = dy, or dy where ymask > 0 and 0 elsewhere (the gradient behind a ReLU whose output is ymask)
   extern __shared__ double red[];  // [R][c][NQ]
   const int c4 = c >> 2;
   const int R = kNormThreads / c4;
@@ -51,7 +53,12 @@ __global__ __launch_bounds__(kNormThreads) void norm_partial_kernel(const float*
     for (int64_t r = r0 + rg; r < r1; r += R) {
       const float4 v = *reinterpret_cast<const float4*>(x + r * c + 4 * col);
       if (dy) {
-        const float4 g = *reinterpret_cast<const float4*>(dy + r * c + 4 * col);
+        float4 g = *reinterpret_cast<const float4*>(dy + r * c + 4 * col);
+        if (ymask) {
+          const float4 y = *reinterpret_cast<const float4*>(ymask + r * c + 4 * col);
+          g.x = y.x > 0.f ? g.x : 0.f; g.y = y.y > 0.f ? g.y : 0.f;
+          g.z = y.z > 0.f ? g.z : 0.f; g.w = y.w > 0.f ? g.w : 0.f;
+        }
         acc[0][0] += g.x; acc[0][1] += (double)g.x * (double)(v.x - mu.x);
         acc[1][0] += g.y; acc[1][1] += (double)g.y * (double)(v.y - mu.y);
         acc[2][0] += g.z; acc[2][1] += (double)g.z * (double)(v.z - mu.z);
@@ -113,6 +120,71 @@ __global__ __launch_bounds__(256) void norm_final_kernel(const double* __restric
   }
 }
 
+// Elementwise passes of the fused normalise + residual + ReLU (BasicBlock.forward,
+// spconv_unet_v1m3_pdnorm.py:121-140: relu(bn(conv(x))) and relu(bn(conv(x)) + residual)); one thread = four
+// consecutive channels of one row, 16-byte accesses.
+//   forward:  y = act(x * a[c] + b[c] + residual),  a = weight * invstd, b = bias - mean * a
+//   backward: g = dy (where y > 0 behind a ReLU, else 0);  dres = g;
+//             dx = (g - sum_g / n - (x - mean) * invstd^2 * sum_g_xmu / n) * invstd * weight
+__global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict__ x, int64_t total4, int c4,
+                                                         const float* __restrict__ mean, const float* __restrict__ var,
+                                                         float eps, const float* __restrict__ weight,
+                                                         const float* __restrict__ bias,
+                                                         const float* __restrict__ residual, int relu,
+                                                         float* __restrict__ y) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total4) return;
+  const int col = (int)(e % c4) * 4;
+  const float4 v = reinterpret_cast<const float4*>(x)[e];
+  float o[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float a = (weight ? weight[col + i] : 1.f) * rsqrtf(var[col + i] + eps);
+    o[i] = (o[i] - mean[col + i]) * a + (bias ? bias[col + i] : 0.f);
+  }
+  if (residual) {
+    const float4 r = reinterpret_cast<const float4*>(residual)[e];
+    o[0] += r.x; o[1] += r.y; o[2] += r.z; o[3] += r.w;
+  }
+  if (relu) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = fmaxf(o[i], 0.f);
+  }
+  reinterpret_cast<float4*>(y)[e] = make_float4(o[0], o[1], o[2], o[3]);
+}
+
+__global__ __launch_bounds__(256) void bn_act_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                         const float* __restrict__ ymask, int64_t total4, int c4,
+                                                         double inv_n, const float* __restrict__ mean,
+                                                         const float* __restrict__ var, float eps,
+                                                         const float* __restrict__ weight,
+                                                         const float* __restrict__ sum_g,
+                                                         const float* __restrict__ sum_g_xmu, float* __restrict__ dx,
+                                                         float* __restrict__ dres) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total4) return;
+  const int col = (int)(e % c4) * 4;
+  const float4 xv = reinterpret_cast<const float4*>(x)[e];
+  const float4 gv = reinterpret_cast<const float4*>(dy)[e];
+  float g[4] = {gv.x, gv.y, gv.z, gv.w};
+  if (ymask) {
+    const float4 yv = reinterpret_cast<const float4*>(ymask)[e];
+    g[0] = yv.x > 0.f ? g[0] : 0.f; g[1] = yv.y > 0.f ? g[1] : 0.f;
+    g[2] = yv.z > 0.f ? g[2] : 0.f; g[3] = yv.w > 0.f ? g[3] : 0.f;
+  }
+  if (dres) reinterpret_cast<float4*>(dres)[e] = make_float4(g[0], g[1], g[2], g[3]);
+  const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+  float o[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float invstd = rsqrtf(var[col + i] + eps);
+    const float k = (float)((double)sum_g_xmu[col + i] * inv_n) * invstd * invstd;
+    const float m = (float)((double)sum_g[col + i] * inv_n);
+    o[i] = (g[i] - m - (xs[i] - mean[col + i]) * k) * invstd * (weight ? weight[col + i] : 1.f);
+  }
+  reinterpret_cast<float4*>(dx)[e] = make_float4(o[0], o[1], o[2], o[3]);
+}
+
 static int norm_blocks(int64_t n, int c) {
   // about 64 KB of input per workgroup, at most kNormMaxBlocks partials
   int64_t rows = (int64_t)65536 / ((int64_t)c * 4);
@@ -124,12 +196,13 @@ static int norm_blocks(int64_t n, int c) {
 }
 
 static int norm_launch(const char* who, const float* x, const float* dy, const float* mean, int64_t n, int c,
-                       float* out0, float* out1, void* d_ws, size_t ws_bytes, hipStream_t stream) {
+                       float* out0, float* out1, void* d_ws, size_t ws_bytes, hipStream_t stream,
+                       const float* ymask = nullptr) {
   M3D_CHECK_ARG(n > 0 && x && out0 && out1, "%s: null pointer or no rows", who);
   M3D_CHECK_ARG(c >= 4 && c % 4 == 0 && c <= 4 * kNormThreads, "%s: channel count %d must be a multiple of 4, at most %d",
                 who, c, 4 * kNormThreads);
   M3D_CHECK_ARG(((uintptr_t)x & 15) == 0 && (dy == nullptr || ((uintptr_t)dy & 15) == 0) &&
-                    (mean == nullptr || ((uintptr_t)mean & 15) == 0),
+                    (mean == nullptr || ((uintptr_t)mean & 15) == 0) && (ymask == nullptr || ((uintptr_t)ymask & 15) == 0),
                 "%s: pointers must be 16-byte aligned", who);
   const int nb = norm_blocks(n, c);
   const size_t need = (size_t)nb * c * 2 * sizeof(double);
@@ -141,7 +214,7 @@ static int norm_launch(const char* who, const float* x, const float* dy, const f
   const size_t lds = (size_t)R * c * 2 * sizeof(double);  // <= 64 rows x 16 B x ... = 16 KB at most
   const int64_t rows_per_block = cdiv(n, nb);
   double* partial = static_cast<double*>(d_ws);
-  hipLaunchKernelGGL((norm_partial_kernel<2>), dim3(nb), dim3(kNormThreads), lds, stream, x, dy, mean, n, c,
+  hipLaunchKernelGGL((norm_partial_kernel<2>), dim3(nb), dim3(kNormThreads), lds, stream, x, dy, mean, ymask, n, c,
                      rows_per_block, partial);
   hipLaunchKernelGGL(norm_final_kernel, dim3((unsigned)cdiv(c, 8)), dim3(256), 0, stream, partial, nb, c, n,
                      dy == nullptr ? 1 : 0, out0, out1);
@@ -189,6 +262,50 @@ extern "C" int m3d_bn_backward_reduce(const float* d_x, const float* d_dy, const
   M3D_CHECK_ARG(d_dy && d_mean, "m3d_bn_backward_reduce: null pointer");
   return norm_launch("m3d_bn_backward_reduce", d_x, d_dy, d_mean, n, c, d_sum_dy, d_sum_dy_xmu, d_ws, ws_bytes,
                      static_cast<hipStream_t>(stream));
+}
+
+extern "C" int m3d_bn_act_backward_reduce(const float* d_x, const float* d_dy, const float* d_y, const float* d_mean,
+                                          int64_t n, int c, float* d_sum_g, float* d_sum_g_xmu, void* d_ws,
+                                          size_t ws_bytes, void* stream) {
+  M3D_CHECK_ARG(d_dy && d_mean, "m3d_bn_act_backward_reduce: null pointer");
+  return norm_launch("m3d_bn_act_backward_reduce", d_x, d_dy, d_mean, n, c, d_sum_g, d_sum_g_xmu, d_ws, ws_bytes,
+                     static_cast<hipStream_t>(stream), d_y);
+}
+
+static int elemt_check(const char* who, int64_t n, int c, const void* a, const void* b, const void* cc, const void* d,
+                       const void* e) {
+  M3D_CHECK_ARG(n > 0 && c >= 4 && c % 4 == 0, "%s: needs rows and a channel count that is a multiple of 4", who);
+  const void* ps[5] = {a, b, cc, d, e};
+  for (const void* p : ps) M3D_CHECK_ARG(((uintptr_t)p & 15) == 0, "%s: pointers must be 16-byte aligned", who);
+  return M3D_OK;
+}
+
+extern "C" int m3d_bn_act_fwd(const float* d_x, int64_t n, int c, const float* d_mean, const float* d_var, float eps,
+                              const float* d_weight, const float* d_bias, const float* d_residual, int relu,
+                              float* d_y, void* stream_) {
+  const char* who = "m3d_bn_act_fwd";
+  M3D_CHECK_ARG(d_x && d_mean && d_var && d_y, "%s: null pointer", who);
+  if (int rc = elemt_check(who, n, c, d_x, d_y, d_residual, nullptr, nullptr)) return rc;
+  const int64_t total4 = n * (c / 4);
+  hipLaunchKernelGGL(bn_act_fwd_kernel, dim3((unsigned)cdiv(total4, 256)), dim3(256), 0, static_cast<hipStream_t>(stream_),
+                     d_x, total4, c / 4, d_mean, d_var, eps, d_weight, d_bias, d_residual, relu, d_y);
+  M3D_LAUNCH_CHECK();
+  return M3D_OK;
+}
+
+extern "C" int m3d_bn_act_backward(const float* d_x, const float* d_dy, const float* d_y, int64_t n, int c,
+                                   const float* d_mean, const float* d_var, float eps, const float* d_weight,
+                                   const float* d_sum_g, const float* d_sum_g_xmu, float* d_dx, float* d_dres,
+                                   void* stream_) {
+  const char* who = "m3d_bn_act_backward";
+  M3D_CHECK_ARG(d_x && d_dy && d_mean && d_var && d_sum_g && d_sum_g_xmu && d_dx, "%s: null pointer", who);
+  if (int rc = elemt_check(who, n, c, d_x, d_dy, d_y, d_dx, d_dres)) return rc;
+  const int64_t total4 = n * (c / 4);
+  hipLaunchKernelGGL(bn_act_bwd_kernel, dim3((unsigned)cdiv(total4, 256)), dim3(256), 0, static_cast<hipStream_t>(stream_),
+                     d_x, d_dy, d_y, total4, c / 4, 1.0 / (double)n, d_mean, d_var, eps, d_weight, d_sum_g, d_sum_g_xmu,
+                     d_dx, d_dres);
+  M3D_LAUNCH_CHECK();
+  return M3D_OK;
 }
 
 extern "C" size_t m3d_bn_stats_static_max_bytes(void) { return kStaticScratchBytes; }

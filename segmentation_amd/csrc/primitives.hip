@@ -307,34 +307,46 @@ int sort_pairs(uint64_t* d_keys, uint32_t* d_vals, uint64_t* d_keys_alt, uint32_
 }
 
 // ------------------------------------------------------------------------------ unique
-__global__ void unique_insert_kernel(const uint64_t* __restrict__ keys, int64_t n,
+__global__ __launch_bounds__(256) void unique_insert_kernel(const uint64_t* __restrict__ keys, int64_t n,
                                      uint64_t* __restrict__ tkeys, int32_t* __restrict__ trep,
                                      uint64_t mask, int32_t* __restrict__ pslot,
                                      uint64_t* __restrict__ ukeys, uint32_t* __restrict__ uslot,
                                      int* __restrict__ d_count) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const uint64_t key = keys[i];
-  uint64_t s = mix64(key) & mask;
-  while (true) {
-    // Most points repeat a key that is already in the table: look before the atomic.  A slot never changes once
-    // it holds a key, so a stale read can only show "empty", which the compare-and-swap then settles.
-    uint64_t old = *reinterpret_cast<const volatile uint64_t*>(&tkeys[s]);
-    if (old == kEmptyKey)
-      old = atomicCAS((unsigned long long*)&tkeys[s], (unsigned long long)kEmptyKey, (unsigned long long)key);
-    if (old == kEmptyKey) {
-      trep[s] = (int32_t)i;
-      const int pos = atomicAdd(d_count, 1);
-      ukeys[pos] = key;
-      uslot[pos] = (uint32_t)s;
-      pslot[i] = (int32_t)s;
-      return;
+  const int lane = threadIdx.x & 63;
+  bool is_new = false;
+  uint64_t key = 0, s = 0;
+  if (i < n) {
+    key = keys[i];
+    s = mix64(key) & mask;
+    while (true) {
+      // Most points repeat a key that is already in the table: look before the atomic.  A slot never changes once
+      // it holds a key, so a stale read can only show "empty", which the compare-and-swap then settles.
+      uint64_t old = *reinterpret_cast<const volatile uint64_t*>(&tkeys[s]);
+      if (old == kEmptyKey)
+        old = atomicCAS((unsigned long long*)&tkeys[s], (unsigned long long)kEmptyKey, (unsigned long long)key);
+      if (old == kEmptyKey) {
+        trep[s] = (int32_t)i;
+        is_new = true;
+        break;
+      }
+      if (old == key) break;
+      s = (s + 1) & mask;
     }
-    if (old == key) {
-      pslot[i] = (int32_t)s;
-      return;
-    }
-    s = (s + 1) & mask;
+    pslot[i] = (int32_t)s;
+  }
+  // The list of distinct keys is appended to once per wave, not once per key: all new keys of a wave take
+  // consecutive positions behind one atomic add on the shared counter.
+  const uint64_t bal = __ballot(is_new);
+  if (bal == 0) return;
+  const int leader = __builtin_ctzll(bal);
+  int base = 0;
+  if (lane == leader) base = atomicAdd(d_count, __popcll(bal));
+  base = __shfl(base, leader, 64);
+  if (is_new) {
+    const int pos = base + __popcll(bal & ((1ull << lane) - 1));
+    ukeys[pos] = key;
+    uslot[pos] = (uint32_t)s;
   }
 }
 

@@ -67,6 +67,84 @@ __global__ __launch_bounds__(256) void subm_probe_kernel(const int4* __restrict_
   if (r >= 0) pair[(int64_t)(26 - k) * n + r] = (int32_t)j;
 }
 
+// --- occupancy-bitmap variant of the submanifold map (grids of at most kBitmapMaxCells cells): the voxels set
+// their bit in a bitmap over the linearised (batch, shape) grid; the rank of a set bit (per-word prefix count +
+// popcount below the bit) numbers the voxels in ascending linear order, and `rowof` maps that number back to the
+// row (rows of level 0 are in hash-key order, rows below it already are in linear order).  A neighbour probe is
+// then one bitmap word, and for a hit one prefix word and one rowof entry - no keys to compare, no probe chains,
+// no table to fill.  The three bitmap kernels are shared with the strided maps (defined below).
+__global__ __launch_bounds__(256) void subm_mark_kernel(const int4* __restrict__ idx, int64_t n, Shape3 sh,
+                                                        int batch_size, unsigned long long* __restrict__ bitmap) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  long long word = -1;  // no early return: every lane takes part in the shuffles
+  unsigned long long bits = 0;
+  if (i < n) {
+    const int4 c = idx[i];
+    if (c.x >= 0 && c.x < batch_size && c.y >= 0 && c.z >= 0 && c.w >= 0 && c.y < sh.s[0] && c.z < sh.s[1] &&
+        c.w < sh.s[2]) {
+      const uint64_t key = lin_key(c.x, c.y, c.z, c.w, sh);
+      word = (long long)(key >> 6);
+      bits = 1ull << (key & 63);
+    }
+  }
+  // rows in linear order put runs of equal words into neighbouring lanes: OR them together before the atomic
+  const long long prev = __shfl_up(word, 1, 64);
+  const bool head = lane == 0 || prev != word;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const long long w = __shfl_down(word, d, 64);
+    const unsigned long long b = __shfl_down(bits, d, 64);
+    if (lane + d < 64 && w == word) bits |= b;
+  }
+  if (head && word >= 0) atomicOr(&bitmap[word], bits);
+}
+
+__device__ inline int bitmap_rank(const unsigned long long* __restrict__ bitmap, const int* __restrict__ prefix,
+                                  uint64_t key) {
+  const unsigned long long w = bitmap[key >> 6];
+  if (!((w >> (key & 63)) & 1ull)) return -1;
+  return prefix[key >> 6] + __popcll(w & ((1ull << (key & 63)) - 1));
+}
+
+__global__ __launch_bounds__(256) void subm_rowof_kernel(const int4* __restrict__ idx, int64_t n, Shape3 sh,
+                                                         int batch_size,
+                                                         const unsigned long long* __restrict__ bitmap,
+                                                         const int* __restrict__ prefix, int32_t* __restrict__ rowof) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const int4 c = idx[j];
+  if (c.x < 0 || c.x >= batch_size || c.y < 0 || c.z < 0 || c.w < 0 || c.y >= sh.s[0] || c.z >= sh.s[1] ||
+      c.w >= sh.s[2])
+    return;
+  rowof[bitmap_rank(bitmap, prefix, lin_key(c.x, c.y, c.z, c.w, sh))] = (int32_t)j;
+}
+
+// grid.y = kernel offset 0 .. 13, mirrored entries as in subm_probe_kernel
+__global__ __launch_bounds__(256) void subm_probe_bitmap_kernel(const int4* __restrict__ idx, int64_t n, Shape3 sh,
+                                                                int batch_size,
+                                                                const unsigned long long* __restrict__ bitmap,
+                                                                const int* __restrict__ prefix,
+                                                                const int32_t* __restrict__ rowof,
+                                                                int32_t* __restrict__ pair) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int k = blockIdx.y;
+  if (j >= n) return;
+  if (k == 13) {
+    pair[(int64_t)13 * n + j] = (int32_t)j;
+    return;
+  }
+  const int4 c = idx[j];
+  const int x = c.y + (k / 9) - 1, y = c.z + ((k / 3) % 3) - 1, z = c.w + (k % 3) - 1;
+  int32_t r = -1;
+  if (c.x >= 0 && c.x < batch_size && x >= 0 && y >= 0 && z >= 0 && x < sh.s[0] && y < sh.s[1] && z < sh.s[2]) {
+    const int rank = bitmap_rank(bitmap, prefix, lin_key(c.x, x, y, z, sh));
+    if (rank >= 0) r = rowof[rank];
+  }
+  pair[(int64_t)k * n + j] = r;
+  if (r >= 0) pair[(int64_t)(26 - k) * n + r] = (int32_t)j;
+}
+
 // ------------------------------------------------------------------------------ strided k2 s2
 // Rows whose parent falls outside the output shape get `drop_key` = one past the largest valid key.
 __global__ void strided_key_kernel(const int4* __restrict__ idx, int64_t n, const int64_t* __restrict__ d_n,
@@ -427,18 +505,71 @@ static int check_shape(const int64_t s[3], const char* who) {
   return M3D_OK;
 }
 
-extern "C" size_t m3d_subm_rulebook_workspace_bytes(int64_t n) {
-  const uint64_t cap = table_cap(n);
-  return align_up(cap * sizeof(uint64_t)) + align_up(cap * sizeof(int32_t));
+// Largest linearised grid (cells) the occupancy-bitmap variants are used for: 32 MiB of bitmap.
+static const uint64_t kBitmapMaxCells = 1ull << 28;
+
+// batch_size * volume when a bitmap over the whole grid is affordable (batch_size >= 1 known), else 0
+static uint64_t subm_bitmap_cells(const int64_t spatial_shape[3], int batch_size) {
+  if (!spatial_shape || batch_size < 1) return 0;
+  long double vol = (long double)batch_size;
+  for (int a = 0; a < 3; ++a) {
+    if (spatial_shape[a] <= 0) return 0;
+    vol *= (long double)spatial_shape[a];
+  }
+  if (!(vol <= (long double)kBitmapMaxCells)) return 0;
+  return (uint64_t)batch_size * (uint64_t)spatial_shape[0] * (uint64_t)spatial_shape[1] * (uint64_t)spatial_shape[2];
 }
 
-extern "C" int m3d_subm_rulebook(const int32_t* d_indices, int64_t n, const int64_t spatial_shape[3],
+extern "C" size_t m3d_subm_rulebook_workspace_bytes(int64_t n, const int64_t spatial_shape[3], int batch_size) {
+  if (n <= 0) n = 1;
+  const uint64_t cap = table_cap(n);
+  size_t hash = align_up(cap * sizeof(uint64_t)) + align_up(cap * sizeof(int32_t));
+  const uint64_t cells = subm_bitmap_cells(spatial_shape, batch_size);
+  if (cells == 0) return hash;
+  const uint64_t nwords = cdiv(cells, 64);
+  size_t bm = align_up(nwords * sizeof(uint64_t)) + align_up(nwords * sizeof(int)) +
+              align_up(cdiv(nwords, kBitmapBlockWords) * sizeof(int)) + align_up(64 * sizeof(int)) +
+              align_up(64 * sizeof(int64_t)) + align_up((size_t)n * sizeof(int32_t));
+  return bm;
+}
+
+extern "C" int m3d_subm_rulebook(const int32_t* d_indices, int64_t n, const int64_t spatial_shape[3], int batch_size,
                                  int32_t* d_pair, void* d_ws, size_t ws_bytes, void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   M3D_CHECK_ARG(n >= 0 && n < (int64_t)INT_MAX, "m3d_subm_rulebook: n out of range");
   if (n == 0) return M3D_OK;
   M3D_CHECK_ARG(d_indices && d_pair && spatial_shape, "m3d_subm_rulebook: null pointer");
   if (int rc = check_shape(spatial_shape, "m3d_subm_rulebook")) return rc;
+  const uint64_t cells = subm_bitmap_cells(spatial_shape, batch_size);
+  if (cells != 0) {
+    const int64_t nwords = (int64_t)cdiv(cells, 64);
+    const int nb = (int)cdiv(nwords, kBitmapBlockWords);
+    Arena a(d_ws, ws_bytes);
+    unsigned long long* bitmap = a.take<unsigned long long>(nwords);
+    int* prefix = a.take<int>(nwords);
+    int* bsum = a.take<int>(nb);
+    int* nout = a.take<int>(64);
+    int64_t* nout64 = a.take<int64_t>(64);
+    int32_t* rowof = a.take<int32_t>(n);
+    if (!a.ok) {
+      set_error("m3d_subm_rulebook: workspace too small (%zu given, %zu needed)", ws_bytes, a.off);
+      return M3D_ENOSPC;
+    }
+    Shape3 sh{{spatial_shape[0], spatial_shape[1], spatial_shape[2]}};
+    const unsigned gb = (unsigned)cdiv(n, 256);
+    const int4* idx = reinterpret_cast<const int4*>(d_indices);
+    M3D_HIP(hipMemsetAsync(bitmap, 0, (size_t)nwords * sizeof(unsigned long long), stream));
+    M3D_HIP(hipMemsetAsync(d_pair + (int64_t)14 * n, 0xFF, (size_t)13 * n * sizeof(int32_t), stream));
+    hipLaunchKernelGGL(subm_mark_kernel, dim3(gb), dim3(256), 0, stream, idx, n, sh, batch_size, bitmap);
+    hipLaunchKernelGGL(bitmap_block_sum_kernel, dim3(nb), dim3(256), 0, stream, bitmap, nwords, bsum);
+    hipLaunchKernelGGL(bitmap_scan_sums_kernel, dim3(1), dim3(256), 0, stream, bsum, nb, nout, nout64);
+    hipLaunchKernelGGL(bitmap_prefix_kernel, dim3(nb), dim3(256), 0, stream, bitmap, nwords, bsum, prefix);
+    hipLaunchKernelGGL(subm_rowof_kernel, dim3(gb), dim3(256), 0, stream, idx, n, sh, batch_size, bitmap, prefix, rowof);
+    hipLaunchKernelGGL(subm_probe_bitmap_kernel, dim3(gb, 14), dim3(256), 0, stream, idx, n, sh, batch_size, bitmap,
+                       prefix, rowof, d_pair);
+    M3D_LAUNCH_CHECK();
+    return M3D_OK;
+  }
   const uint64_t cap = table_cap(n);
   Arena a(d_ws, ws_bytes);
   uint64_t* tkeys = a.take<uint64_t>(cap);
@@ -460,9 +591,6 @@ extern "C" int m3d_subm_rulebook(const int32_t* d_indices, int64_t n, const int6
   M3D_LAUNCH_CHECK();
   return M3D_OK;
 }
-
-// Largest linearised output grid (cells) the occupancy-bitmap variant is used for: 32 MiB of bitmap.
-static const uint64_t kBitmapMaxCells = 1ull << 28;
 
 static bool strided_cells(const int64_t spatial_shape[3], int batch_size, uint64_t* cells) {
   if (!spatial_shape || batch_size < 1) return false;

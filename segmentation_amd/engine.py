@@ -137,10 +137,10 @@ class SpUNetEngine:
         w[:c, 0] = emb
         self.text = _Conv(ops.pack_weight(w, self.head_precision), None, None)
         self.n_classes = c
-        # one-kernel head (last 1x1 layer + logits + argmax): 2-term split precision and supported shapes only
+        # one-kernel head (last 1x1 layer + logits + argmax): 2- and 3-term split precisions, supported shapes only
         self.text_fused = None
-        if self._terms == 2 and self.fuse_head and ops.head_fused_supported(self.final.w.cin, c):
-            self.text_fused = ops.head_pack_text(emb, cin=self.final.w.cin)
+        if self._terms in (2, 3) and self.fuse_head and ops.head_fused_supported(self.final.w.cin, c):
+            self.text_fused = ops.head_pack_text(emb, cin=self.final.w.cin, terms=self._terms)
         # folded head: logits = x96 . (E Wf)^T + E bf   (no nonlinearity between `final` and the head)
         wf = self._sd["final.weight"].reshape(self.final.cout, -1).double().to(self.device)
         wfold = torch.zeros((cpad, 1, wf.shape[1]), dtype=torch.float32, device=self.device)
@@ -167,7 +167,7 @@ class SpUNetEngine:
         levels = []
         chain_done = ops.strided_chain(voxel_coords, spatial_shape, batch_size, self.num_stages, defer=True)
         # level 0 needs nothing from the chain: its map and schedule keep the GPU busy while the counts travel
-        pair0 = ops.subm_rulebook(voxel_coords, list(spatial_shape))
+        pair0 = ops.subm_rulebook(voxel_coords, list(spatial_shape), batch_size)
         sched0 = self._subm_schedule(0, pair0, voxel_coords.shape[0], voxel_coords, list(spatial_shape), batch_size)
         chain = chain_done()
         idx, shape = voxel_coords, list(spatial_shape)
@@ -187,7 +187,7 @@ class SpUNetEngine:
             if l == 0:
                 lv.pair_subm, lv.subm = pair0, sched0
             else:
-                lv.pair_subm = ops.subm_rulebook(lv.indices, lv.shape)
+                lv.pair_subm = ops.subm_rulebook(lv.indices, lv.shape, batch_size)
                 lv.subm = self._subm_schedule(l, lv.pair_subm, lv.n, lv.indices, lv.shape, batch_size)
             if lv.pair_fwd is not None:
                 lv.down = ops.build_schedule(lv.pair_fwd, lv.n_next, None, 0)

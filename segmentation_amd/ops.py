@@ -125,8 +125,9 @@ def voxelize(coord, feat, offset, grid_size, pad=128, hash_method="fnv", grid_mo
 
 
 # ----------------------------------------------------------------------------- kernel maps
-def subm_rulebook(indices, spatial_shape):
-    """SubM k3 kernel map: pair [27, N] i32 (reference call sites: v1m3:98-117,205-212)."""
+def subm_rulebook(indices, spatial_shape, batch_size=0):
+    """SubM k3 kernel map: pair [27, N] i32 (reference call sites: v1m3:98-117,205-212).  batch_size (every batch
+    index is below it) lets grids of up to 2^28 cells use the occupancy-bitmap lookup; 0 = unknown (hash table)."""
     lib = _lib.load()
     _need_cuda(indices)
     indices = indices.contiguous()
@@ -135,8 +136,8 @@ def subm_rulebook(indices, spatial_shape):
     pair = torch.empty((27, n), dtype=torch.int32, device=indices.device)
     if n == 0:
         return pair
-    ws = _workspace(lib.m3d_subm_rulebook_workspace_bytes(n), indices.device)
-    rc = lib.m3d_subm_rulebook(_ptr(indices), n, _shape3(spatial_shape), _ptr(pair), _ptr(ws),
+    ws = _workspace(lib.m3d_subm_rulebook_workspace_bytes(n, _shape3(spatial_shape), int(batch_size)), indices.device)
+    rc = lib.m3d_subm_rulebook(_ptr(indices), n, _shape3(spatial_shape), int(batch_size), _ptr(pair), _ptr(ws),
                                ws.numel(), _stream())
     _lib.check(rc, "m3d_subm_rulebook")
     return pair
@@ -514,6 +515,38 @@ def bn_backward_reduce(x, dy, mean):
     return sum_dy, sum_dy_xmu
 
 
+def bn_act_fwd(x, mean, var, eps, weight, bias, residual=None, relu=True):
+    """y = relu?(batch_norm(x; mean, biased var, eps, weight, bias) + residual) in one pass (m3d_bn_act_fwd)."""
+    lib = _lib.load()
+    _need_cuda(x, mean, var, weight, bias, residual)
+    n, c = x.shape
+    y = torch.empty_like(x)
+    rc = lib.m3d_bn_act_fwd(_ptr(x), n, c, _ptr(mean), _ptr(var), float(eps), _ptr(weight), _ptr(bias), _ptr(residual),
+                            int(bool(relu)), _ptr(y), _stream())
+    _lib.check(rc, "m3d_bn_act_fwd")
+    return y
+
+
+def bn_act_backward(x, dy, y, mean, var, eps, weight, want_dres):
+    """Backward of bn_act_fwd: returns (dx, dres or None, sum_g, sum_g_xmu); y = the forward output when a ReLU was
+    applied, else None."""
+    lib = _lib.load()
+    _need_cuda(x, dy, y, mean, var, weight)
+    n, c = x.shape
+    sum_g = torch.empty((c,), dtype=torch.float32, device=x.device)
+    sum_g_xmu = torch.empty((c,), dtype=torch.float32, device=x.device)
+    ws = _workspace(lib.m3d_bn_workspace_bytes(n, c), x.device)
+    rc = lib.m3d_bn_act_backward_reduce(_ptr(x), _ptr(dy), _ptr(y), _ptr(mean), n, c, _ptr(sum_g), _ptr(sum_g_xmu),
+                                        _ptr(ws), ws.numel(), _stream())
+    _lib.check(rc, "m3d_bn_act_backward_reduce")
+    dx = torch.empty_like(x)
+    dres = torch.empty_like(x) if want_dres else None
+    rc = lib.m3d_bn_act_backward(_ptr(x), _ptr(dy), _ptr(y), n, c, _ptr(mean), _ptr(var), float(eps), _ptr(weight),
+                                 _ptr(sum_g), _ptr(sum_g_xmu), _ptr(dx), _ptr(dres), _stream())
+    _lib.check(rc, "m3d_bn_act_backward")
+    return dx, dres, sum_g, sum_g_xmu
+
+
 def argmax_rows(logits, n_classes):
     lib = _lib.load()
     _need_cuda(logits)
@@ -528,13 +561,14 @@ def argmax_rows(logits, n_classes):
 class PackedText:
     """Text embeddings in the layout of the fused head kernel."""
 
-    def __init__(self, data, n_classes, classes_padded, cmid):
-        self.data, self.n_classes, self.classes_padded, self.cmid = data, n_classes, classes_padded, cmid
+    def __init__(self, data, n_classes, classes_padded, cmid, terms=2):
+        self.data, self.n_classes, self.classes_padded, self.cmid, self.terms = data, n_classes, classes_padded, cmid, terms
 
 
-def head_pack_text(text, cin=96, classes_padded=None):
-    """text [n_classes, cmid] f32 -> PackedText.  The class count is padded to what the fused kernel for `cin`
-    input channels takes: a multiple of 32 for 96 channels, 128 or 256 otherwise."""
+def head_pack_text(text, cin=96, classes_padded=None, terms=2):
+    """text [n_classes, cmid] f32 -> PackedText in the split format of `terms` (2 or 3) terms.  The class count is
+    padded to what the fused kernel for `cin` input channels takes: a multiple of 32 for 96 channels, 128 or 256
+    otherwise."""
     lib = _lib.load()
     _need_cuda(text)
     text = text.contiguous().float()
@@ -542,10 +576,12 @@ def head_pack_text(text, cin=96, classes_padded=None):
     cp = classes_padded or ((c + 31) // 32 * 32 if cin == 96 else (128 if c <= 128 else 256))
     if c > cp or d % 32 != 0:
         raise ValueError(f"head_pack_text: {c} classes x {d} channels not supported")
-    out = torch.empty((lib.m3d_head_text_bytes(cp, d),), dtype=torch.uint8, device=text.device)
-    rc = lib.m3d_head_pack_text(_ptr(text), c, d, cp, _ptr(out), _stream())
-    _lib.check(rc, "m3d_head_pack_text")
-    return PackedText(out, c, cp, d)
+    if terms not in (2, 3):
+        raise ValueError("head_pack_text: the fused head exists for 2 and 3 terms")
+    out = torch.empty((lib.m3d_head_text_bytes_terms(cp, d, terms),), dtype=torch.uint8, device=text.device)
+    rc = lib.m3d_head_pack_text_terms(_ptr(text), c, d, cp, terms, _ptr(out), _stream())
+    _lib.check(rc, "m3d_head_pack_text_terms")
+    return PackedText(out, c, cp, d, terms)
 
 
 def head_fused_supported(cin, n_classes):
@@ -556,7 +592,8 @@ def head_fused(x: "SplitTensor", w1: "PackedWeight", text: PackedText, scale=Non
                want_labels=True):
     """Last 1x1 layer + text logits + row argmax in one kernel.  Returns (voxel_label or None, logits or None)."""
     lib = _lib.load()
-    assert x.terms == 2 and w1.precision == "bf16x3" and w1.k == 1 and w1.cout == text.cmid and w1.cin == x.c
+    assert x.terms in (2, 3) and x.terms == text.terms and w1.precision == PRECISION_OF_TERMS[x.terms]
+    assert w1.k == 1 and w1.cout == text.cmid and w1.cin == x.c
     n, dev = x.n, x.data.device
     label = torch.empty((n,), dtype=torch.int32, device=dev) if want_labels else None
     logits = torch.empty((n, text.classes_padded), dtype=torch.float32, device=dev) if want_logits else None
@@ -564,10 +601,10 @@ def head_fused(x: "SplitTensor", w1: "PackedWeight", text: PackedText, scale=Non
     if PROFILE is not None:
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         ev[0].record()
-    rc = lib.m3d_head_fused_sf32(_ptr(x.data), x.c, n, _ptr(w1.data), _ptr(scale), _ptr(shift), text.cmid,
-                                 _ptr(text.data), text.classes_padded, text.n_classes, _ptr(logits),
-                                 text.classes_padded, _ptr(label), _stream())
-    _lib.check(rc, "m3d_head_fused_sf32")
+    rc = lib.m3d_head_fused_terms(_ptr(x.data), x.c, n, x.terms, _ptr(w1.data), _ptr(scale), _ptr(shift), text.cmid,
+                                  _ptr(text.data), text.classes_padded, text.n_classes, _ptr(logits),
+                                  text.classes_padded, _ptr(label), _stream())
+    _lib.check(rc, "m3d_head_fused_terms")
     if ev is not None:
         ev[1].record()
         flops = 2.0 * n * text.cmid * (x.c + text.n_classes)

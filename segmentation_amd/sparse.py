@@ -224,7 +224,7 @@ class SparseConvolution(SparseModule):
         if self.subm:
             if self.kernel_size != [3, 3, 3] or self.dilation != [1, 1, 1]:
                 raise NotImplementedError("SubMConv3d supports kernel_size 3 (and 1), dilation 1")
-            pair = ops.subm_rulebook(x.indices, x.spatial_shape)
+            pair = ops.subm_rulebook(x.indices, x.spatial_shape, x.batch_size)
             data = ImplicitGemmIndiceData(pair_fwd=pair, pair_bwd=None, out_indices=x.indices, indices=x.indices,
                                           out_spatial_shape=x.spatial_shape, spatial_shape=x.spatial_shape,
                                           ksize=self.kernel_size, stride=self.stride, padding=self.padding,

@@ -49,7 +49,7 @@ def test_argument_validation_without_gpu():
     assert lib.m3d_sf32_bytes(10, 64, 2) == 11 * 64 * 4
     shape = (ctypes.c_int64 * 3)(0, 4, 4)
     one = ctypes.c_void_p(8)  # never dereferenced: the shape check fails first
-    rc = lib.m3d_subm_rulebook(one, 5, shape, one, null, 0, null)
+    rc = lib.m3d_subm_rulebook(one, 5, shape, 1, one, null, 0, null)
     assert rc == -1 and b"spatial_shape" in lib.m3d_last_error()
     assert lib.m3d_schedule_npad(1) == 256 and lib.m3d_schedule_npad(257) == 512
     assert lib.m3d_halo_cap() == 640 and lib.m3d_halo_tile_rows() == 256

@@ -19,20 +19,35 @@ def _voxels(seed, target, batch=1):
     return oracle.sparsify(b["coord"], b["feat"], b["offset"], 0.02)
 
 
+# lookup: "bitmap" = batch size known and the grid small enough for the occupancy bitmap, "hash" = batch size
+# unknown (0): the open-addressing table
+@pytest.mark.parametrize("lookup", ["bitmap", "hash"])
 @pytest.mark.parametrize("seed,target,batch", [(0, 2000, 1), (1, 40000, 1), (2, 5000, 3)])
-def test_subm_rulebook_bit_exact(device, seed, target, batch):
+def test_subm_rulebook_bit_exact(device, seed, target, batch, lookup):
     sp = _voxels(seed, target, batch)
     idx = torch.from_numpy(sp["voxel_coords"]).to(device)
-    pair = ops.subm_rulebook(idx, sp["spatial_shape"])
+    pair = ops.subm_rulebook(idx, sp["spatial_shape"], sp["batch_size"] if lookup == "bitmap" else 0)
     ref = oracle.subm_rulebook(sp["voxel_coords"], sp["spatial_shape"])
     assert np.array_equal(pair.cpu().numpy(), ref)
+    # the levels below the first come in ascending linear order (bit rank == row)
+    oi, oshape, _, _ = ops.strided_rulebook(idx, sp["spatial_shape"], sp["batch_size"])
+    pair1 = ops.subm_rulebook(oi.contiguous(), oshape, sp["batch_size"] if lookup == "bitmap" else 0)
+    assert np.array_equal(pair1.cpu().numpy(), oracle.subm_rulebook(oi.cpu().numpy(), oshape))
 
 
-def test_subm_rulebook_respects_bounds_and_batches(device):
+@pytest.mark.parametrize("batch_size", [0, 2])
+def test_subm_rulebook_respects_bounds_and_batches(device, batch_size):
     # neighbours across the spatial boundary or in another batch must not pair
     idx = np.array([[0, 0, 0, 0], [0, 0, 0, 1], [1, 0, 0, 1], [0, 3, 3, 3], [1, 3, 3, 2]], dtype=np.int32)
-    pair = ops.subm_rulebook(torch.from_numpy(idx).to(device), [4, 4, 4])
+    pair = ops.subm_rulebook(torch.from_numpy(idx).to(device), [4, 4, 4], batch_size)
     assert np.array_equal(pair.cpu().numpy(), oracle.subm_rulebook(idx, [4, 4, 4]))
+
+
+def test_subm_rulebook_large_grid_falls_back_to_the_hash_table(device):
+    # 2^30 cells: no bitmap; rows far apart and at the upper corner of the grid
+    idx = np.array([[0, 1023, 1023, 1023], [0, 1023, 1023, 1022], [0, 0, 0, 0], [0, 1, 1, 1], [0, 512, 512, 512]], dtype=np.int32)
+    pair = ops.subm_rulebook(torch.from_numpy(idx).to(device), [1024, 1024, 1024], 1)
+    assert np.array_equal(pair.cpu().numpy(), oracle.subm_rulebook(idx, [1024, 1024, 1024]))
 
 
 @pytest.mark.parametrize("seed,target,batch", [(0, 2000, 1), (1, 40000, 1), (2, 5000, 3)])
