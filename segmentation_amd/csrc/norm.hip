@@ -126,31 +126,46 @@ __global__ __launch_bounds__(256) void norm_final_kernel(const double* __restric
 //   forward:  y = act(x * a[c] + b[c] + residual),  a = weight * invstd, b = bias - mean * a
 //   backward: g = dy (where y > 0 behind a ReLU, else 0);  dres = g;
 //             dx = (g - sum_g / n - (x - mean) * invstd^2 * sum_g_xmu / n) * invstd * weight
+constexpr int kElemtIters = 8;  // float4 elements per thread; one block covers 256 * kElemtIters of them
+
+// Per-channel coefficients are formed once per block in LDS (c <= 1024 channels), so the streaming loop holds no
+// division, square root or 64-bit remainder: an element's channel group advances by 256 % c4 per iteration.
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict__ x, int64_t total4, int c4,
                                                          const float* __restrict__ mean, const float* __restrict__ var,
                                                          float eps, const float* __restrict__ weight,
                                                          const float* __restrict__ bias,
                                                          const float* __restrict__ residual, int relu,
                                                          float* __restrict__ y) {
-  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= total4) return;
-  const int col = (int)(e % c4) * 4;
-  const float4 v = reinterpret_cast<const float4*>(x)[e];
-  float o[4] = {v.x, v.y, v.z, v.w};
+  extern __shared__ float4 coef[];  // [3][c4]: mean, scale, bias ((x - mean) first: no cancellation when |mean| >> std)
+  float* cf = reinterpret_cast<float*>(coef);
+  const int c = c4 * 4;
+  for (int j = threadIdx.x; j < c; j += 256) {
+    cf[j] = mean[j];
+    cf[c + j] = (weight ? weight[j] : 1.f) * rsqrtf(var[j] + eps);
+    cf[2 * c + j] = bias ? bias[j] : 0.f;
+  }
+  __syncthreads();
+  const int64_t base = (int64_t)blockIdx.x * (256 * kElemtIters);
+  int col = (int)((base + threadIdx.x) % c4);
+  const int step = 256 % c4;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const float a = (weight ? weight[col + i] : 1.f) * rsqrtf(var[col + i] + eps);
-    o[i] = (o[i] - mean[col + i]) * a + (bias ? bias[col + i] : 0.f);
+  for (int it = 0; it < kElemtIters; ++it) {
+    const int64_t e = base + it * 256 + threadIdx.x;
+    if (e < total4) {
+      const float4 v = reinterpret_cast<const float4*>(x)[e];
+      const float4 mu = coef[col], a = coef[c4 + col], b = coef[2 * c4 + col];
+      float4 o = make_float4((v.x - mu.x) * a.x + b.x, (v.y - mu.y) * a.y + b.y, (v.z - mu.z) * a.z + b.z,
+                             (v.w - mu.w) * a.w + b.w);
+      if (residual) {
+        const float4 r = reinterpret_cast<const float4*>(residual)[e];
+        o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+      }
+      if (relu) o = make_float4(fmaxf(o.x, 0.f), fmaxf(o.y, 0.f), fmaxf(o.z, 0.f), fmaxf(o.w, 0.f));
+      reinterpret_cast<float4*>(y)[e] = o;
+    }
+    col += step;
+    if (col >= c4) col -= c4;
   }
-  if (residual) {
-    const float4 r = reinterpret_cast<const float4*>(residual)[e];
-    o[0] += r.x; o[1] += r.y; o[2] += r.z; o[3] += r.w;
-  }
-  if (relu) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) o[i] = fmaxf(o[i], 0.f);
-  }
-  reinterpret_cast<float4*>(y)[e] = make_float4(o[0], o[1], o[2], o[3]);
 }
 
 __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
@@ -161,28 +176,44 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const float* __restrict
                                                          const float* __restrict__ sum_g,
                                                          const float* __restrict__ sum_g_xmu, float* __restrict__ dx,
                                                          float* __restrict__ dres) {
-  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= total4) return;
-  const int col = (int)(e % c4) * 4;
-  const float4 xv = reinterpret_cast<const float4*>(x)[e];
-  const float4 gv = reinterpret_cast<const float4*>(dy)[e];
-  float g[4] = {gv.x, gv.y, gv.z, gv.w};
-  if (ymask) {
-    const float4 yv = reinterpret_cast<const float4*>(ymask)[e];
-    g[0] = yv.x > 0.f ? g[0] : 0.f; g[1] = yv.y > 0.f ? g[1] : 0.f;
-    g[2] = yv.z > 0.f ? g[2] : 0.f; g[3] = yv.w > 0.f ? g[3] : 0.f;
+  // dx = (g - m - (x - mean) * k) * s = g * s - (x - mean) * (k * s) - m * s
+  extern __shared__ float4 coef[];  // [4][c4]: s, k * s, mean, m * s
+  float* cf = reinterpret_cast<float*>(coef);
+  const int c = c4 * 4;
+  for (int j = threadIdx.x; j < c; j += 256) {
+    const float invstd = rsqrtf(var[j] + eps);
+    const float k = (float)((double)sum_g_xmu[j] * inv_n) * invstd * invstd;
+    const float m = (float)((double)sum_g[j] * inv_n);
+    const float sc = invstd * (weight ? weight[j] : 1.f);
+    cf[j] = sc;
+    cf[c + j] = k * sc;
+    cf[2 * c + j] = mean[j];
+    cf[3 * c + j] = m * sc;
   }
-  if (dres) reinterpret_cast<float4*>(dres)[e] = make_float4(g[0], g[1], g[2], g[3]);
-  const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
-  float o[4];
+  __syncthreads();
+  const int64_t base = (int64_t)blockIdx.x * (256 * kElemtIters);
+  int col = (int)((base + threadIdx.x) % c4);
+  const int step = 256 % c4;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const float invstd = rsqrtf(var[col + i] + eps);
-    const float k = (float)((double)sum_g_xmu[col + i] * inv_n) * invstd * invstd;
-    const float m = (float)((double)sum_g[col + i] * inv_n);
-    o[i] = (g[i] - m - (xs[i] - mean[col + i]) * k) * invstd * (weight ? weight[col + i] : 1.f);
+  for (int it = 0; it < kElemtIters; ++it) {
+    const int64_t e = base + it * 256 + threadIdx.x;
+    if (e < total4) {
+      const float4 xv = reinterpret_cast<const float4*>(x)[e];
+      float4 g = reinterpret_cast<const float4*>(dy)[e];
+      if (ymask) {
+        const float4 yv = reinterpret_cast<const float4*>(ymask)[e];
+        g.x = yv.x > 0.f ? g.x : 0.f; g.y = yv.y > 0.f ? g.y : 0.f;
+        g.z = yv.z > 0.f ? g.z : 0.f; g.w = yv.w > 0.f ? g.w : 0.f;
+      }
+      if (dres) reinterpret_cast<float4*>(dres)[e] = g;
+      const float4 s = coef[col], ks = coef[c4 + col], mu = coef[2 * c4 + col], t = coef[3 * c4 + col];
+      reinterpret_cast<float4*>(dx)[e] =
+          make_float4(g.x * s.x - (xv.x - mu.x) * ks.x - t.x, g.y * s.y - (xv.y - mu.y) * ks.y - t.y,
+                      g.z * s.z - (xv.z - mu.z) * ks.z - t.z, g.w * s.w - (xv.w - mu.w) * ks.w - t.w);
+    }
+    col += step;
+    if (col >= c4) col -= c4;
   }
-  reinterpret_cast<float4*>(dx)[e] = make_float4(o[0], o[1], o[2], o[3]);
 }
 
 static int norm_blocks(int64_t n, int c) {
@@ -274,7 +305,8 @@ extern "C" int m3d_bn_act_backward_reduce(const float* d_x, const float* d_dy, c
 
 static int elemt_check(const char* who, int64_t n, int c, const void* a, const void* b, const void* cc, const void* d,
                        const void* e) {
-  M3D_CHECK_ARG(n > 0 && c >= 4 && c % 4 == 0, "%s: needs rows and a channel count that is a multiple of 4", who);
+  M3D_CHECK_ARG(n > 0 && c >= 4 && c % 4 == 0 && c <= 1024,
+                "%s: needs rows and a channel count that is a multiple of 4, at most 1024", who);
   const void* ps[5] = {a, b, cc, d, e};
   for (const void* p : ps) M3D_CHECK_ARG(((uintptr_t)p & 15) == 0, "%s: pointers must be 16-byte aligned", who);
   return M3D_OK;
@@ -287,7 +319,8 @@ extern "C" int m3d_bn_act_fwd(const float* d_x, int64_t n, int c, const float* d
   M3D_CHECK_ARG(d_x && d_mean && d_var && d_y, "%s: null pointer", who);
   if (int rc = elemt_check(who, n, c, d_x, d_y, d_residual, nullptr, nullptr)) return rc;
   const int64_t total4 = n * (c / 4);
-  hipLaunchKernelGGL(bn_act_fwd_kernel, dim3((unsigned)cdiv(total4, 256)), dim3(256), 0, static_cast<hipStream_t>(stream_),
+  hipLaunchKernelGGL(bn_act_fwd_kernel, dim3((unsigned)cdiv(total4, 256 * kElemtIters)), dim3(256),
+                     (size_t)3 * c * sizeof(float), static_cast<hipStream_t>(stream_),
                      d_x, total4, c / 4, d_mean, d_var, eps, d_weight, d_bias, d_residual, relu, d_y);
   M3D_LAUNCH_CHECK();
   return M3D_OK;
@@ -301,7 +334,8 @@ extern "C" int m3d_bn_act_backward(const float* d_x, const float* d_dy, const fl
   M3D_CHECK_ARG(d_x && d_dy && d_mean && d_var && d_sum_g && d_sum_g_xmu && d_dx, "%s: null pointer", who);
   if (int rc = elemt_check(who, n, c, d_x, d_dy, d_y, d_dx, d_dres)) return rc;
   const int64_t total4 = n * (c / 4);
-  hipLaunchKernelGGL(bn_act_bwd_kernel, dim3((unsigned)cdiv(total4, 256)), dim3(256), 0, static_cast<hipStream_t>(stream_),
+  hipLaunchKernelGGL(bn_act_bwd_kernel, dim3((unsigned)cdiv(total4, 256 * kElemtIters)), dim3(256),
+                     (size_t)4 * c * sizeof(float), static_cast<hipStream_t>(stream_),
                      d_x, d_dy, d_y, total4, c / 4, 1.0 / (double)n, d_mean, d_var, eps, d_weight, d_sum_g, d_sum_g_xmu,
                      d_dx, d_dres);
   M3D_LAUNCH_CHECK();

@@ -48,13 +48,16 @@ class PDBatchNorm(nn.Module):
             raise AssertionError(f"unknown condition {condition!r}")
         return self.bns[self.conditions.index(condition)]
 
-    def forward(self, feat, condition=None, context=None):
+    def forward(self, feat, condition=None, context=None, residual=None, relu=False):
+        """The reference's forward, plus what its callers apply to the result (v1m3:121-140): `residual` is added
+        and a ReLU applied when asked for, inside the normalisation's own elementwise pass where that runs on the
+        library's kernels."""
         bn = self.pick(condition)
         if not self.adaptive:
-            return bn(feat)
+            return _batch_norm_with(bn, feat, bn.weight, bn.bias, residual, relu)
         pre = self.__dict__.pop("_affine", None)  # set for one call by SpUNet.forward (all norms in one product)
         if pre is not None and feat.dim() == 2:
-            return _batch_norm_with(bn, feat, pre[0], pre[1])
+            return _batch_norm_with(bn, feat, pre[0], pre[1], residual, relu)
         assert context is not None
         shift, scale = self.modulation(context).chunk(2, dim=1)
         if bn.affine and shift.shape[0] == 1 and feat.dim() == 2:
@@ -62,8 +65,14 @@ class PDBatchNorm(nn.Module):
             # norm with weight gamma*(1+scale) and bias beta*(1+scale)+shift, so the two [N, C] elementwise passes
             # (and the three of their backward) become operations on [C] vectors.
             gain = 1.0 + scale[0]
-            return _batch_norm_with(bn, feat, bn.weight * gain, bn.bias * gain + shift[0])
-        return bn(feat) * (1.0 + scale) + shift
+            return _batch_norm_with(bn, feat, bn.weight * gain, bn.bias * gain + shift[0], residual, relu)
+        return _finish(bn(feat) * (1.0 + scale) + shift, residual, relu)
+
+
+def _finish(y, residual, relu):
+    if residual is not None:
+        y = y + residual
+    return F.relu(y) if relu else y
 
 
 _BN_KERNEL_ROWS = int(os.environ.get("M3D_BN_KERNEL_ROWS", "20000"))
@@ -71,38 +80,36 @@ _COUNTS = {}
 
 
 class _BatchNormTrainFn(torch.autograd.Function):
-    """Batch-statistics normalisation of x [n, c] with the column reductions on the library's kernels
-    (m3d_bn_stats, m3d_bn_backward_reduce) and torch's elementwise kernels of synchronised batch norm for the
-    rest.  Returns (y, mean, biased variance); only y is differentiable."""
+    """y = relu?(batch-statistics normalisation of x [n, c] + residual) on the library's kernels: the column
+    reductions (m3d_bn_stats, m3d_bn_act_backward_reduce) and one elementwise pass each way (m3d_bn_act_fwd,
+    m3d_bn_act_backward); the ReLU's mask is read back from the saved output.  Returns (y, mean, biased
+    variance); only y is differentiable."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, eps):
+    def forward(ctx, x, weight, bias, eps, residual, relu):
         x = x.contiguous()
+        if residual is not None:
+            residual = residual.contiguous()
         mean, var = ops.bn_stats(x)
-        invstd = torch.rsqrt(var + eps)
-        y = torch.batch_norm_elemt(x, weight, bias, mean, invstd, eps)
-        ctx.save_for_backward(x, weight, mean, invstd)
+        y = ops.bn_act_fwd(x, mean, var, eps, weight, bias, residual, relu)
+        ctx.save_for_backward(x, weight, mean, var, y if relu else None)
+        ctx.eps, ctx.has_weight, ctx.has_bias = eps, weight is not None, bias is not None
+        ctx.want_dres = residual is not None and ctx.needs_input_grad[4]
         ctx.mark_non_differentiable(mean, var)
         return y, mean, var
 
     @staticmethod
     def backward(ctx, dy, _dmean, _dvar):
-        x, weight, mean, invstd = ctx.saved_tensors
-        dy = dy.contiguous()
-        sum_dy, sum_dy_xmu = ops.bn_backward_reduce(x, dy, mean)
-        key = (x.device, x.shape[0])
-        count = _COUNTS.get(key)
-        if count is None:
-            if len(_COUNTS) > 64:
-                _COUNTS.clear()
-            count = _COUNTS[key] = torch.tensor([x.shape[0]], dtype=torch.int32, device=x.device)
-        dx = torch.batch_norm_backward_elemt(dy, x, mean, invstd, weight, sum_dy, sum_dy_xmu, count)
-        return dx, sum_dy_xmu * invstd, sum_dy, None
+        x, weight, mean, var, y = ctx.saved_tensors
+        dx, dres, sum_g, sum_g_xmu = ops.bn_act_backward(x, dy.contiguous(), y, mean, var, ctx.eps, weight,
+                                                         ctx.want_dres)
+        dweight = sum_g_xmu * torch.rsqrt(var + ctx.eps) if ctx.has_weight else None
+        return dx, dweight, sum_g if ctx.has_bias else None, None, dres, None
 
 
-def _batch_norm_with(bn, x, weight, bias):
+def _batch_norm_with(bn, x, weight, bias, residual=None, relu=False):
     """nn.BatchNorm1d.forward of `bn` with another affine pair: same statistics, running-average update and
-    batch counter."""
+    batch counter; then + residual and ReLU if asked for."""
     factor = 0.0 if bn.momentum is None else bn.momentum
     if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
         bn.num_batches_tracked.add_(1)
@@ -113,14 +120,15 @@ def _batch_norm_with(bn, x, weight, bias):
     n = x.shape[0]
     if (use_batch_stats and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.shape[1] % 4 == 0
             and x.shape[1] <= 1024 and _BN_KERNEL_ROWS and n >= _BN_KERNEL_ROWS):
-        y, mean, var = _BatchNormTrainFn.apply(x, weight, bias, bn.eps)
+        y, mean, var = _BatchNormTrainFn.apply(x, weight, bias, bn.eps, residual, relu)
         if keep_running and bn.running_mean is not None:
             with torch.no_grad():
                 bn.running_mean.lerp_(mean, factor)
                 bn.running_var.lerp_(var * (n / (n - 1.0)), factor)
         return y
-    return F.batch_norm(x, bn.running_mean if keep_running else None, bn.running_var if keep_running else None,
-                        weight, bias, use_batch_stats, factor, bn.eps)
+    y = F.batch_norm(x, bn.running_mean if keep_running else None, bn.running_var if keep_running else None,
+                     weight, bias, use_batch_stats, factor, bn.eps)
+    return _finish(y, residual, relu)
 
 
 class ConvNormAct(nn.Module):
@@ -135,7 +143,7 @@ class ConvNormAct(nn.Module):
     def forward(self, x):
         x, condition, context = x
         out = self.conv(x)
-        return out.replace_feature(self.relu(self.bn(out.features, condition, context)))
+        return out.replace_feature(self.bn(out.features, condition, context, relu=True))
 
 
 class BasicBlock(sparse.SparseModule):
@@ -158,14 +166,14 @@ class BasicBlock(sparse.SparseModule):
     def forward(self, x):
         x, condition, context = x
         out = self.conv1(x)
-        out = out.replace_feature(self.relu(self.bn1(out.features, condition, context)))
+        out = out.replace_feature(self.bn1(out.features, condition, context, relu=True))
         out = self.conv2(out)
-        feats = self.bn2(out.features, condition, context)
         if self.in_channels == self.embed_channels:
             res = x.features
         else:
             res = self.proj_norm(self.proj_conv(x).features, condition, context)
-        return out.replace_feature(self.relu(feats + res)), condition, context
+        return out.replace_feature(self.bn2(out.features, condition, context, residual=res, relu=True)), \
+            condition, context
 
 
 class SpUNet(nn.Module):
@@ -176,6 +184,9 @@ class SpUNet(nn.Module):
         super().__init__()
         # voxelizer options of spconv_unet_v1m1_base.SpUNetBase (v1m1:177-178, :335-339); v1m3 always runs the defaults
         self.hash_method, self.pooling_method, self.pooling_seed = hash_method, pooling_method, pooling_seed
+        # True: forward stops in front of `final` and returns its input as sparse_conv_feat (for callers that fold
+        # the last, 1x1x1 convolution into what follows: train.caption_loss_folded)
+        self.skip_final = False
         assert len(layers) % 2 == 0 and len(layers) == len(channels)
         self.in_channels, self.out_channels = in_channels, out_channels
         self.base_channels, self.channels, self.layers = base_channels, tuple(channels), tuple(layers)
@@ -312,7 +323,8 @@ class SpUNet(nn.Module):
             skip = skips.pop(-1)
             x = x.replace_feature(torch.cat((x.features, skip.features), dim=1))
             x, _, _ = self.dec[s]([x, condition, context])
-        x = self.final(x)
+        if not self.skip_final:
+            x = self.final(x)
         return dict(sparse_conv_feat=x, feat=x.features, v2p_map=vox["v2p_map"], voxel=vox)
 
 

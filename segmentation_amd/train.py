@@ -83,6 +83,74 @@ def caption_loss(point_features, text_features, labels_per_segment, point_indice
     if normalize:
         point_features = F.normalize(point_features, dim=-1)
     logits = point_features @ text_features.T.to(device)
+    return _loss_from_logits(logits, labels_per_segment, point_indices, caption_offsets, num_points_per_caption,
+                             logit_scale, reduction, row_map)
+
+
+class _TallMatmul(torch.autograd.Function):
+    """x [N, C] @ m [C, U] for N in the hundreds of thousands and small C, U.  The gradient of m reduces over N;
+    as one GEMM it has C*U/tile-size workgroups (a few dozen) and runs on a fraction of the chip, so it is formed as
+    a batched product over row ranges and summed in range order (deterministic)."""
+
+    RANGES = 64
+
+    @staticmethod
+    def forward(ctx, x, m):
+        ctx.save_for_backward(x, m)
+        return x @ m
+
+    @staticmethod
+    def backward(ctx, g):
+        x, m = ctx.saved_tensors
+        dx = dm = None
+        if ctx.needs_input_grad[0]:
+            dx = g @ m.T
+        if ctx.needs_input_grad[1]:
+            n, r = x.shape[0], _TallMatmul.RANGES
+            if n < 64 * r:
+                dm = x.T @ g
+            else:
+                main = n // r * r
+                g = g.contiguous()
+                dm = torch.bmm(x[:main].view(r, main // r, -1).transpose(1, 2), g[:main].view(r, main // r, -1)).sum(0)
+                if main < n:
+                    dm = dm + x[main:].T @ g[main:]
+        return dx, dm
+
+
+def caption_loss_folded(pre_features, weight, bias, text_features, labels_per_segment, point_indices, caption_offsets,
+                        num_points_per_caption, normalize: bool = True, logit_scale: Optional[torch.Tensor] = None,
+                        reduction: str = "weighted_sum", row_map: Optional[torch.Tensor] = None):
+    """caption_loss of features = pre_features @ weight.T + bias (the network's last, 1x1x1 convolution:
+    spconv_unet_v1m3_pdnorm.py:318-320) without forming them.  With C_in = 96 inputs, D = 768 outputs and U texts,
+        features @ text.T      = pre @ (weight.T @ text.T) + bias @ text.T            [N, U] from a [C_in, U] matrix
+        |features|^2 per row   = rowsum((pre @ G) * pre) + 2 pre @ (weight.T @ bias) + |bias|^2,  G = weight.T @ weight
+    so the [N, D] tensor, its normalisation and the two [N, D] x [D, U] products of the loss (forward and backward)
+    become [N, C_in]-sized work; autograd carries the gradient to weight and bias through the small matrices."""
+    device = pre_features.device
+    w = weight.reshape(weight.shape[0], -1)  # [D, C_in]
+    text = text_features.to(device)
+    pre_features = pre_features.contiguous()
+    logits = _TallMatmul.apply(pre_features, w.T @ text.T)
+    if bias is not None:
+        logits = logits + bias @ text.T
+    if normalize:
+        quad = _TallMatmul.apply(pre_features, w.T @ w)
+        if bias is not None:
+            # the linear term rides on the quadratic one (a matrix-vector product over [N, C_in] as a call of its
+            # own runs far below memory speed in the BLAS library)
+            sq = ((quad + 2.0 * (bias @ w)) * pre_features).sum(1) + bias @ bias
+        else:
+            sq = (quad * pre_features).sum(1)
+        # F.normalize: x / max(|x|, 1e-12)
+        logits = logits * (1.0 / sq.clamp_min(0.0).sqrt().clamp_min(1e-12))[:, None]
+    return _loss_from_logits(logits, labels_per_segment, point_indices, caption_offsets, num_points_per_caption,
+                             logit_scale, reduction, row_map)
+
+
+def _loss_from_logits(logits, labels_per_segment, point_indices, caption_offsets, num_points_per_caption, logit_scale,
+                      reduction, row_map):
+    device = logits.device
     if logit_scale is not None:
         logits = logit_scale.exp() * logits
     scores = F.log_softmax(logits, dim=-1)
@@ -264,8 +332,13 @@ class TrainStep:
     def __init__(self, model: torch.nn.Module, total_steps: int, lr: float = 5e-2, momentum: float = 0.9,
                  weight_decay: float = 1e-4, pct_start: float = 0.05, div_factor: float = 10.0,
                  final_div_factor: float = 1000.0, dist=None, use_logit_scale: bool = False, mix_prob: float = 0.0,
-                 seed: int = 0, overlap_allreduce: bool = True):
+                 seed: int = 0, overlap_allreduce: bool = True, fold_head: bool = True):
         self.model = model
+        # fold_head: the loss is computed from the input of the backbone's last 1x1x1 convolution
+        # (caption_loss_folded); needs a backbone with `final` and `skip_final` (spunet.SpUNet)
+        backbone = getattr(model, "backbone", model)
+        self._fold_backbone = backbone if fold_head and hasattr(backbone, "skip_final") and \
+            getattr(getattr(backbone, "final", None), "conv1x1", False) else None
         self.dist = dist
         # language_module.py:212-214: with probability mix_prob neighbouring samples of the batch are merged in pairs
         self.mix_prob = mix_prob
@@ -299,10 +372,22 @@ class TrainStep:
         return cache[ci]
 
     def loss(self, batch: Dict):
+        cd = batch["caption_data"]
+        bb = self._fold_backbone
+        if bb is not None:
+            bb.skip_final = True
+            try:
+                out = self.model(batch)
+            finally:
+                bb.skip_final = False
+            text, seg_labels, _ = unique_text_features(cd["embedding"])
+            return caption_loss_folded(out["sparse_conv_feat"].features, bb.final.weight, bb.final.bias, text,
+                                       seg_labels, cd["point_indices"], cd["caption_offsets"],
+                                       cd["num_points_per_caption"], logit_scale=self.logit_scale,
+                                       row_map=out["v2p_map"])
         out = self.model(batch)
         feats = out["sparse_conv_feat"].features if isinstance(out, dict) else out.sparse_conv_feat.features
         v2p = out["v2p_map"] if isinstance(out, dict) else out.v2p_map
-        cd = batch["caption_data"]
         text, seg_labels, _ = unique_text_features(cd["embedding"])
         # clip_feat = feats[v2p] (language_module.py:205) is applied inside the loss as a row map
         return caption_loss(feats, text, seg_labels, cd["point_indices"], cd["caption_offsets"],

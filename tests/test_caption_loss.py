@@ -67,6 +67,38 @@ def test_row_map_and_unknown_reduction():
         train.caption_loss(vox, text, labels, pi, offsets, w, row_map=v2p, reduction="sum")
 
 
+@pytest.mark.parametrize("normalize,with_bias,scaled", [(True, True, False), (True, False, True), (False, True, True)])
+def test_folded_last_layer_equals_loss_of_its_output(normalize, with_bias, scaled, monkeypatch):
+    """caption_loss_folded(pre, W, b, ...) == caption_loss(pre @ W.T + b, ...) with all gradients, in float64."""
+    rng = np.random.default_rng(11)
+    n, cin, d, u = 400, 12, 40, 9
+    monkeypatch.setattr(train._TallMatmul, "RANGES", 3)  # 400 rows = 3 ranges of 133 + a tail of 1
+    pre = torch.from_numpy(rng.normal(size=(n, cin))).requires_grad_(True)
+    w = torch.from_numpy(rng.normal(size=(d, 1, 1, 1, cin)) * 0.3).requires_grad_(True)  # the 1x1x1 kernel's layout
+    b = torch.from_numpy(rng.normal(size=(d,)) * 0.2).requires_grad_(True) if with_bias else None
+    scale = torch.tensor(np.log(1 / 0.07), dtype=torch.float64, requires_grad=True) if scaled else None
+    text = F.normalize(torch.from_numpy(rng.normal(size=(u, d))), dim=1)
+    v2p = torch.from_numpy(rng.integers(0, n, size=1500))
+    counts = torch.tensor([200, 0, 31, 77, 1, 400])
+    offsets = torch.cat([torch.zeros(1, dtype=torch.int64), counts.cumsum(0)])
+    pi = torch.from_numpy(rng.integers(0, 1500, size=int(counts.sum())))
+    labels = torch.from_numpy(rng.integers(0, u, size=counts.numel()))
+    weights = counts.double() + 1.0
+    leaves = [t for t in (pre, w, b, scale) if t is not None]
+    got = train.caption_loss_folded(pre, w, b, text, labels, pi, offsets, weights, normalize=normalize,
+                                    logit_scale=scale, row_map=v2p)
+    g_got = torch.autograd.grad(got, leaves)
+    feats = pre @ w.reshape(d, cin).T
+    if b is not None:
+        feats = feats + b
+    ref = train.caption_loss(feats, text, labels, pi, offsets, weights, normalize=normalize, logit_scale=scale,
+                             row_map=v2p)
+    g_ref = torch.autograd.grad(ref, leaves)
+    assert abs(got.item() - ref.item()) < 1e-12 * max(1.0, abs(ref.item()))
+    for a, r in zip(g_got, g_ref):
+        assert torch.allclose(a, r, rtol=1e-9, atol=1e-13)
+
+
 @pytest.mark.parametrize("tie_on_leading_columns", [False, True])
 def test_unique_rows_equals_numpy_unique_axis0(tie_on_leading_columns):
     """The device routine of unique_text_features (hash grouping + leading-column order, verified, with a

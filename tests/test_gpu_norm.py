@@ -68,3 +68,39 @@ def test_training_mode_pdnorm_matches_float64(device, n):
     bn, bnr = m.pick("ScanNet"), ref.pick("ScanNet")
     assert _rel(bn.running_mean, bnr.running_mean) < 1e-5 and _rel(bn.running_var, bnr.running_var) < 1e-5
     assert bn.num_batches_tracked.item() == 1
+
+
+@pytest.mark.parametrize("n", [300, 40000])
+@pytest.mark.parametrize("with_res,relu", [(False, True), (True, True), (True, False)])
+def test_pdnorm_with_residual_and_relu_matches_float64(device, n, with_res, relu):
+    """relu(bn(x) + residual) in one pass each way (BasicBlock.forward, spconv_unet_v1m3_pdnorm.py:121-140) against
+    the same expression in float64 on the CPU; the row count selects the kernel path or torch's."""
+    torch.manual_seed(5)
+    m = spunet.PDBatchNorm(96, adaptive=True)
+    for bn in m.bns:
+        bn.weight.data.normal_()
+        bn.bias.data.normal_()
+    m.modulation[-1].weight.data.normal_(std=0.05)
+    ref = copy.deepcopy(m).double().train()
+    m = m.to(device).train()
+    x, res = torch.randn(n, 96) * 1.5 - 0.5, torch.randn(n, 96)
+    ctx, gout = torch.randn(1, 256), torch.randn(n, 96)
+    xg, rg = x.to(device).requires_grad_(True), res.to(device).requires_grad_(True)
+    y = m(xg, "Matterport3D", ctx.to(device), residual=rg if with_res else None, relu=relu)
+    xr, rr = x.double().requires_grad_(True), res.double().requires_grad_(True)
+    yr = ref(xr, "Matterport3D", ctx.double())
+    if with_res:
+        yr = yr + rr
+    if relu:
+        # an element within rounding distance of the ReLU's kink may fall on either side in f32: no gradient there
+        gout = gout * (yr.detach().abs() > 1e-4).float()
+        yr = F.relu(yr)
+    y.backward(gout.to(device))
+    yr.backward(gout.double())
+    assert _rel(y.detach(), yr.detach()) < 1e-5
+    assert _rel(xg.grad, xr.grad) < 1e-5
+    if with_res:
+        assert _rel(rg.grad, rr.grad) < 1e-6
+    for (name, p), (_, q) in zip(m.named_parameters(), ref.named_parameters()):
+        if q.grad is not None:
+            assert _rel(p.grad, q.grad) < 1e-4, name

@@ -180,7 +180,8 @@ def test_caption_loss_row_map_equals_gathered_rows(device):
 from _refmodel import CpuConvs as _CpuConvs  # noqa: E402  (sparse convolutions through the CPU oracle)
 
 
-def test_whole_training_step_matches_cpu_oracle(device, monkeypatch):
+@pytest.mark.parametrize("fold_head", [True, False])
+def test_whole_training_step_matches_cpu_oracle(device, monkeypatch, fold_head):
     torch.manual_seed(0)
     cfg = dict(spunet.SPUNET18A, out_channels=64, channels=(32, 64, 64, 96, 96, 64, 32, 32), layers=(1, 1, 1, 1, 1, 1, 1, 1))
     net = spunet.PPT(spunet.SpUNet(in_channels=cfg["in_channels"], out_channels=cfg["out_channels"],
@@ -194,7 +195,8 @@ def test_whole_training_step_matches_cpu_oracle(device, monkeypatch):
     cd = _caption_batch(rng, n, 10, 64, device)
     batch = dict(coord=torch.from_numpy(sc["coord"]).to(device), feat=torch.from_numpy(sc["feat"]).to(device),
                  offset=torch.tensor([0, n]), grid_size=0.02, condition=["ScanNet"], caption_data=cd)
-    step = train.TrainStep(net, total_steps=10)
+    step = train.TrainStep(net, total_steps=10, fold_head=fold_head)
+    assert (step._fold_backbone is not None) == fold_head
     net.train()
     loss = step.loss(batch)
     loss.backward()
