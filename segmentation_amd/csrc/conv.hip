@@ -18,6 +18,8 @@
 //
 // HBM/L2 layout: activations [rows, C] f32 row-major (a gathered row slab is one full 128-B
 // line), weights [k][Cout][Cin] so that a weight slab is also 128 B per output channel.
+#include <mutex>
+#include <type_traits>
 #include "conv_shared.h"
 
 #include <stdlib.h>
@@ -381,20 +383,27 @@ struct UnitIt {  // position in the unit sequence of a tile: kernel offset k (lo
   int k, cc;
 };
 
-template <int WM, int WN, int NT, int T, int NBUF>
+// AF: the activations are plain f32 rows (s0 / s1 = [rows][C] f32, no zero row: missing neighbours read zbuf) and
+// the terms are formed in registers after the fragment read (T == 2 or 3); the weights are split as always.
+template <int WM, int WN, int NT, int T, int NBUF, bool AF>
 __device__ __forceinline__ void conv_igemm_dma_body(const ConvArgs& a) {
-  using G = DmaGeom<T>;
+  using G = DmaGeom<T>;                                                        // weight image
+  // activation image: 16 f32 channels are 64 bytes (T = 3); 32 f32 channels are the 128 bytes of the two-term unit
+  using GA = typename std::conditional<AF && T == 3, DmaGeomF32, DmaGeom<T>>::type;
+  static_assert(!AF || T == 3 || T == 2, "f32 activations: two- and three-term products only");
+  static_assert(GA::G == G::G && GA::UPS == G::UPS, "activation and weight units cover the same channels");
   constexpr int BM = 32 * WM, BN = 32 * NT * WN, NTHR = 64 * WM * WN;
-  constexpr int A_BYTES = BM * G::ROWB, W_BYTES = BN * G::ROWB, BUF = A_BYTES + W_BYTES;
+  constexpr int A_BYTES = BM * GA::ROWB, W_BYTES = BN * G::ROWB, BUF = A_BYTES + W_BYTES;
   // DMA instructions per thread and stage; where the slot count does not divide by the thread count the last
   // instruction is issued by the leading waves only (and its last wave by its leading lanes)
-  constexpr int A_V = (BM * G::SLOTS + NTHR - 1) / NTHR, W_V = (BN * G::SLOTS + NTHR - 1) / NTHR;
-  constexpr int GRPB = G::PIECES * 16;  // bytes of one (row, unit) in HBM
+  constexpr int A_V = (BM * GA::SLOTS + NTHR - 1) / NTHR, W_V = (BN * G::SLOTS + NTHR - 1) / NTHR;
+  constexpr int GRPB = G::PIECES * 16;   // bytes of one (output channel, unit) of the weights in HBM
+  constexpr int GRPA = GA::PIECES * 16;  // bytes of one (row, unit) of the activations in HBM
   constexpr int UPS = G::UPS;
   static_assert(A_BYTES % 256 == 0 && BUF % 256 == 0, "every image starts on a bank line");
   // slot lists that divide evenly by the thread count and have no unused slot need no lane mask
-  constexpr bool A_EXACT = BM * G::SLOTS % NTHR == 0, W_EXACT = BN * G::SLOTS % NTHR == 0;
-  constexpr bool NO_DEAD = G::PIECES * UPS == G::SLOTS;
+  constexpr bool A_EXACT = BM * GA::SLOTS % NTHR == 0, W_EXACT = BN * G::SLOTS % NTHR == 0;
+  constexpr bool NO_DEAD = G::PIECES * UPS == G::SLOTS && GA::PIECES * UPS == GA::SLOTS;
   static_assert(NBUF >= 2 && NBUF <= 4, "ring depth");
   extern __shared__ __align__(16) char ldsb[];
   constexpr int RING = NBUF * BUF > BM * BN * 4 ? NBUF * BUF : BM * BN * 4;  // the output tile is staged here too
@@ -409,7 +418,7 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvArgs& a) {
   const int nchunk = (a.c0 + a.c1) / G::G;
   const int g0 = a.c0 / G::G;
   const char* wsplit = reinterpret_cast<const char*>(a.weight);
-  const uint32_t rowb0 = (uint32_t)g0 * GRPB, rowb1 = (uint32_t)(a.c1 / G::G) * GRPB;
+  const uint32_t rowb0 = (uint32_t)g0 * GRPA, rowb1 = (uint32_t)(a.c1 / G::G) * GRPA;
 
   uint32_t bmask, wmask;
   conv_masks<WM>(a, tile_base, wm, bmask, wmask);
@@ -446,11 +455,11 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvArgs& a) {
 #pragma unroll
   for (int v = 0; v < A_V; ++v) {
     const int e = v * NTHR + tid;
-    a_r[v] = e / G::SLOTS;
-    const int p = (e % G::SLOTS) ^ G::swz(a_r[v]);
-    a_u[v] = UPS == 2 && p >= G::PIECES;
+    a_r[v] = e / GA::SLOTS;
+    const int p = (e % GA::SLOTS) ^ GA::swz(a_r[v]);
+    a_u[v] = UPS == 2 && p >= GA::PIECES;
     a_p[v] = (uint32_t)(UPS == 2 ? p & 3 : p) * 16u;
-    a_on[v] = e < BM * G::SLOTS && p < G::PIECES * UPS;
+    a_on[v] = e < BM * GA::SLOTS && p < GA::PIECES * UPS;
   }
   uint32_t w_o[W_V];
   bool w_on[W_V], w_u[W_V];
@@ -487,7 +496,7 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvArgs& a) {
   // DMA instructions this wave issues per stage (the same for every stage): the counted waits below depend on it
   int gw = 0;
 #pragma unroll
-  for (int v = 0; v < A_V; ++v) gw += (v * NTHR + wave * 64 < BM * G::SLOTS) ? 1 : 0;
+  for (int v = 0; v < A_V; ++v) gw += (v * NTHR + wave * 64 < BM * GA::SLOTS) ? 1 : 0;
 #pragma unroll
   for (int v = 0; v < W_V; ++v) gw += (v * NTHR + wave * 64 < BN * G::SLOTS) ? 1 : 0;
   auto issue_next = [&](int bi) {
@@ -502,7 +511,7 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvArgs& a) {
     for (int u = 0; u < UPS; ++u) {
       on[u] = issued < nunit;
       const bool first = it.cc < g0;
-      src[u] = (first ? a.s0 : a.s1) + (first ? it.cc : it.cc - g0) * GRPB;
+      src[u] = (first ? a.s0 : a.s1) + (first ? it.cc : it.cc - g0) * GRPA;
       rowb[u] = first ? rowb0 : rowb1;
       zero[u] = (int)(first ? a.zero0 : a.zero1);
       wsrc[u] = wsplit + ((uint64_t)it.k * wk_stride + (uint32_t)it.cc * GRPB);
@@ -517,7 +526,8 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvArgs& a) {
       const int z = u1 ? zero[UPS - 1] : zero[0];
       const uint32_t row = (uint32_t)(a_id[v] < 0 ? z : a_id[v]);
       const char* g = (u1 ? src[UPS - 1] : src[0]) + ((uint64_t)row * (u1 ? rowb[UPS - 1] : rowb[0]) + a_p[v]);
-      if (A_EXACT || v * NTHR + wave * 64 < BM * G::SLOTS) {  // wave-uniform: this instruction exists for this wave
+      if (AF && a_id[v] < 0) g = a.zbuf + a_p[v];
+      if (A_EXACT || v * NTHR + wave * 64 < BM * GA::SLOTS) {  // wave-uniform: this instruction exists for this wave
         if (((A_EXACT && NO_DEAD) || a_on[v]) && (UPS == 1 || !u1 || on[UPS - 1]))
           __builtin_amdgcn_global_load_lds(g, (lds_ptr_t)(buf + (v * NTHR + wave * 64) * 16), 16, 0, 0);
       }
@@ -544,7 +554,10 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvArgs& a) {
   uint32_t a_off[NQ], w_off[NT][NQ];
 #pragma unroll
   for (int q = 0; q < NQ; ++q) {
-    a_off[q] = arow * G::ROWB + (((2 * q + h) ^ G::swz(arow)) * 16);
+    // f32 rows: the lane's eight consecutive channels of k-step ks are pieces 4 ks + 2h and 4 ks + 2h + 1
+    // (T = 3: q = 0, 1, one k-step; T = 2: q = 2 ks + 0, 1)
+    a_off[q] = AF ? arow * GA::ROWB + (((4 * (q >> 1) + 2 * h + (q & 1)) ^ GA::swz(arow)) * 16)
+                  : arow * GA::ROWB + (((2 * q + h) ^ GA::swz(arow)) * 16);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       const int j = (wn * NT + nt) * 32 + r32;
@@ -575,8 +588,21 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvArgs& a) {
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         bf16x8 af[2];
+        if constexpr (AF) {
+          const float4 lo = *reinterpret_cast<const float4*>(buf + a_off[2 * ks]);
+          const float4 hi = *reinterpret_cast<const float4*>(buf + a_off[2 * ks + 1]);
+          float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
 #pragma unroll
-        for (int t = 0; t < 2; ++t) af[t] = *reinterpret_cast<const bf16x8*>(buf + a_off[t * 2 + ks]);
+          for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+              af[t][i] = (__bf16)v[i];
+              v[i] -= (float)af[t][i];
+            }
+        } else {
+#pragma unroll
+          for (int t = 0; t < 2; ++t) af[t] = *reinterpret_cast<const bf16x8*>(buf + a_off[t * 2 + ks]);
+        }
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
           bf16x8 bf[2];
@@ -590,8 +616,21 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvArgs& a) {
     } else {
       if (!m0) return;
       bf16x8 af[3];
+      if constexpr (AF) {
+        const float4 lo = *reinterpret_cast<const float4*>(buf + a_off[0]);
+        const float4 hi = *reinterpret_cast<const float4*>(buf + a_off[1]);
+        float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
 #pragma unroll
-      for (int t = 0; t < 3; ++t) af[t] = *reinterpret_cast<const bf16x8*>(buf + a_off[t]);
+        for (int t = 0; t < 3; ++t)  // term t = bf16 rounding of what the earlier terms left over (as store_split)
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            af[t][i] = (__bf16)v[i];
+            v[i] -= (float)af[t][i];
+          }
+      } else {
+#pragma unroll
+        for (int t = 0; t < 3; ++t) af[t] = *reinterpret_cast<const bf16x8*>(buf + a_off[t]);
+      }
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
         bf16x8 bf[3];
@@ -704,9 +743,9 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvArgs& a) {
   }
 }
 
-template <int WM, int WN, int NT, int T, int NBUF>
+template <int WM, int WN, int NT, int T, int NBUF, bool AF = false>
 __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_dma_kernel(ConvArgs a) {
-  conv_igemm_dma_body<WM, WN, NT, T, NBUF>(a);
+  conv_igemm_dma_body<WM, WN, NT, T, NBUF, AF>(a);
 }
 
 // f32 [n][c] -> sf32 [n + 1][c/32][terms][32] bf16 (row n zero).  One thread per element.
@@ -905,16 +944,40 @@ static int launch_split(const ConvArgs& a, int nz, hipStream_t stream) {
   return M3D_OK;
 }
 
-template <int WM, int WN, int NT, int T, int NBUF>
+template <int WM, int WN, int NT, int T, int NBUF, bool AF = false>
 static int launch_dma_n(const ConvArgs& a, int nz, hipStream_t stream) {
   constexpr int BM = 32 * WM, BN = 32 * NT * WN, NTHR = 64 * WM * WN;
-  constexpr size_t ring = (size_t)NBUF * (BM + BN) * DmaGeom<T>::ROWB, tile = (size_t)BM * BN * sizeof(float);
+  constexpr int A_ROWB = AF && T == 3 ? DmaGeomF32::ROWB : DmaGeom<T>::ROWB;
+  constexpr size_t ring = (size_t)NBUF * (BM * A_ROWB + BN * DmaGeom<T>::ROWB), tile = (size_t)BM * BN * sizeof(float);
   const size_t lds = (ring > tile ? ring : tile) + (size_t)(a.kvol + 1) * BM * sizeof(int);
   static LdsGrant grant;
-  if (int rc = grant.ensure(reinterpret_cast<const void*>(&conv_igemm_dma_kernel<WM, WN, NT, T, NBUF>), lds)) return rc;
+  if (int rc = grant.ensure(reinterpret_cast<const void*>(&conv_igemm_dma_kernel<WM, WN, NT, T, NBUF, AF>), lds)) return rc;
   dim3 grid((unsigned)(a.npad / BM), (unsigned)(a.cout / BN), (unsigned)nz);
-  hipLaunchKernelGGL((conv_igemm_dma_kernel<WM, WN, NT, T, NBUF>), grid, dim3(NTHR), lds, stream, a);
+  hipLaunchKernelGGL((conv_igemm_dma_kernel<WM, WN, NT, T, NBUF, AF>), grid, dim3(NTHR), lds, stream, a);
   M3D_LAUNCH_CHECK();
+  return M3D_OK;
+}
+
+// Zero bytes for the gathers of missing neighbours when the activations are plain f32 rows (one copy per device,
+// never written).
+static __device__ __align__(256) char conv_zero_bytes[256];
+
+static int conv_zero_ptr(const char** out) {
+  static std::mutex mu;
+  static const char* ptr[64] = {};
+  int dev = 0;
+  M3D_HIP(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 64) {
+    set_error("conv: device index %d out of range", dev);
+    return M3D_EINVAL;
+  }
+  std::lock_guard<std::mutex> lock(mu);
+  if (ptr[dev] == nullptr) {
+    void* p = nullptr;
+    M3D_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(conv_zero_bytes)));
+    ptr[dev] = static_cast<const char*>(p);
+  }
+  *out = ptr[dev];
   return M3D_OK;
 }
 
@@ -992,7 +1055,7 @@ extern "C" size_t m3d_conv_workspace_bytes(int64_t n, int cout, int k) {
 }
 
 // mode: 0 exact f32; 1/2/5 bf16 products with the f32 activations split inside the kernel (T = 2/3/1);
-// 3/4/6 LDS-DMA on sf32 inputs (T = 2/3/1)
+// 3/4/6 LDS-DMA on sf32 inputs (T = 2/3/1); 7/8 LDS-DMA on f32 inputs, terms formed after the fragment read (T = 3/2)
 static int run_conv(ConvArgs& a, int mode, bool mfma_ok, void* d_ws, size_t ws_bytes, hipStream_t stream,
                     const char* who) {
   a.slab = nullptr;
@@ -1022,7 +1085,7 @@ static int run_conv(ConvArgs& a, int mode, bool mfma_ok, void* d_ws, size_t ws_b
         a.cout % (32 * q.nt * q.wn) == 0 && a.npad % (32 * q.wm) == 0 && q.nz >= 1 && q.nz <= a.kvol)
       p = q;
   }
-  const bool dma = mode == 3 || mode == 4 || mode == 6;
+  const bool dma = mode == 3 || mode == 4 || mode == 6 || mode == 7 || mode == 8;
   if (dma && p.wm == 1 && p.wn == 3) p = ConvPlan{1, 1, 3, p.nz};  // equal DMA count per wave
   if (p.nz > 1) {
     const size_t need = (size_t)p.nz * a.npad * a.cout * sizeof(float);
@@ -1045,6 +1108,8 @@ static int run_conv(ConvArgs& a, int mode, bool mfma_ok, void* d_ws, size_t ws_b
     if (mode == 3) rc = launch_dma<WM_, WN_, NT_, 2>(a, p.nz, stream);              \
     else if (mode == 4) rc = launch_dma<WM_, WN_, NT_, 3>(a, p.nz, stream);         \
     else if (mode == 6) rc = launch_dma<WM_, WN_, NT_, 1>(a, p.nz, stream);         \
+    else if (mode == 7) rc = launch_dma_n<WM_, WN_, NT_, 3, 2, true>(a, p.nz, stream); \
+    else if (mode == 8) rc = launch_dma_n<WM_, WN_, NT_, 2, 2, true>(a, p.nz, stream); \
   }
   if (!dma) {
     M3D_CASE(4, 1, 1) M3D_CASE(4, 1, 2) M3D_CASE(4, 1, 3) M3D_CASE(4, 1, 4)
@@ -1126,7 +1191,19 @@ extern "C" int m3d_conv_fwd_f32(const float* d_in0, int c0, const float* d_in1, 
   // slabs whose sum is a multiple of 32 but which are not multiples themselves have no kernel
   M3D_CHECK_ARG(precision == M3D_PREC_F32 || mfma_ok || (c0 + c1) % 32 != 0 || cout % 32 != 0,
                 "%s: with a bf16 precision both input slabs (%d, %d) must be multiples of 32 channels", who, c0, c1);
-  return run_conv(a, precision == M3D_PREC_BF16 ? 5 : precision, mfma_ok, d_ws, ws_bytes, stream, who);
+  int mode = precision == M3D_PREC_BF16 ? 5 : precision;
+  // split products: the f32 rows go to LDS as they are (M3D_F32_DMA=0: split in registers on the way to LDS)
+  static const bool f32_dma = [] {
+    const char* e = getenv("M3D_F32_DMA");
+    return !(e && e[0] == '0');
+  }();
+  if ((mode == 1 || mode == 2) && mfma_ok && f32_dma) {
+    mode = mode == 2 ? 7 : 8;
+    a.s0 = reinterpret_cast<const char*>(d_in0);
+    a.s1 = reinterpret_cast<const char*>(d_in1);
+    if (int rc = conv_zero_ptr(&a.zbuf)) return rc;
+  }
+  return run_conv(a, mode, mfma_ok, d_ws, ws_bytes, stream, who);
 }
 
 extern "C" int m3d_conv_fwd_sf32(const void* d_in0, int c0, int64_t rows0, const void* d_in1, int c1,

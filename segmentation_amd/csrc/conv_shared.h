@@ -28,6 +28,7 @@ struct ConvArgs {
   char* out_split;       // optional sf32 copy of the output (cout/32 groups per row)
   int terms;             // T of out_split
   const int32_t* tile_order;  // optional: tile taken by workgroup blockIdx.x of a 128-row-tile launch
+  const char* zbuf;           // >= 64 zero bytes: what a missing neighbour gathers when s0 / s1 are plain f32 rows
 };
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -269,6 +270,18 @@ struct DmaGeom {
   static constexpr int SLOTS = T == 3 ? 6 : 8;
   static constexpr int ROWB = SLOTS * 16;
   __device__ static inline int swz(int r) { return T == 3 ? ((r >> 3) & 1) : ((r >> 1) & 7); }
+};
+
+// Activations as plain f32 rows [rows][C] for the three-term products: a unit is 16 channels = 64 bytes = 4 pieces of
+// one row (two thirds of the bytes of the pre-split form); the terms are formed in registers after the fragment read.
+// Rows r, r + 4, r + 8, r + 12 start on the same banks and take the four XOR patterns.
+struct DmaGeomF32 {
+  static constexpr int G = 16;
+  static constexpr int UPS = 1;
+  static constexpr int PIECES = 4;
+  static constexpr int SLOTS = 4;
+  static constexpr int ROWB = 64;
+  __device__ static inline int swz(int r) { return (r >> 2) & 3; }
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;

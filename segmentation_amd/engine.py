@@ -282,19 +282,24 @@ class SpUNetEngine:
         return out, vox
 
     @torch.no_grad()
-    def predict(self, coord, feat, offset, grid_size, fold_head=False, return_logits=False):
+    def predict(self, coord, feat, offset, grid_size, fold_head=False, return_logits=False, return_features=False):
         """Per-point labels (int64), like logits.max(1)[1] on clip_feat @ emb_target.T.  return_logits adds the
         per-voxel logits of the features as they are (CLIPAlignmentEval with normalize_input=False, as
         configs/model/loss/caption.yaml:7 sets it; normalising the rows first scales every row of logits by a
-        positive number and leaves the labels unchanged)."""
+        positive number and leaves the labels unchanged).  return_features adds the per-voxel 768-d features of the
+        same pass as "voxel_feat" (clip_feat of language_module.py:205 is voxel_feat[v2p_map], the record
+        language_module.py:349-356 saves); the last layer then writes them out instead of keeping them on chip."""
         if self.text is None:
             raise RuntimeError("call set_text_embeddings() first")
+        if return_features and fold_head:
+            raise ValueError("fold_head never forms the features; it cannot return them")
         with torch.cuda.device(self.device):
-            return self._predict(coord, feat, offset, grid_size, fold_head, return_logits)
+            return self._predict(coord, feat, offset, grid_size, fold_head, return_logits, return_features)
 
-    def _predict(self, coord, feat, offset, grid_size, fold_head, return_logits):
+    def _predict(self, coord, feat, offset, grid_size, fold_head, return_logits, return_features=False):
         vlabel = None
-        if self.text_fused is not None and not fold_head:
+        vfeat = None
+        if self.text_fused is not None and not fold_head and not return_features:
             # `final`, the logits and the argmax in one kernel: the CLIP features stay on chip
             vox, levels = self._voxelize_and_maps(coord, feat, offset, grid_size)
             x = self.backbone(vox["voxel_feats"], levels)
@@ -311,8 +316,9 @@ class SpUNetEngine:
         else:
             # the head consumes the split features directly; the f32 copy is only written when asked for
             pair, vox = self._forward_features(coord, feat, offset, grid_size, want_split=self._terms != 0,
-                                               want_f32=False)
+                                               want_f32=return_features)
             src = pair[1] if self._terms else pair
+            vfeat = pair[0] if self._terms else pair
             logits = ops.conv_fwd(src, self.text.w, None, self.last_stats["n_voxels"][0], flop_cout=self.n_classes)
         if vlabel is None:
             vlabel = ops.argmax_rows(logits, self.n_classes)
@@ -320,4 +326,6 @@ class SpUNetEngine:
         out = dict(pred=plabel, voxel_pred=vlabel, v2p_map=vox["v2p_map"], n_voxels=vox["n_voxels"])
         if return_logits:
             out["voxel_logits"] = logits[:, :self.n_classes]
+        if return_features:
+            out["voxel_feat"] = vfeat
         return out

@@ -133,3 +133,51 @@ def test_all_tile_configurations(device, target, terms):
         ref = oracle.subm_conv(x, w, pair.cpu().numpy())
         out = ops.conv_fwd(ops.split_f32(x.to(device), terms), ops.pack_weight(w, PREC[terms], device), sched, n)
         assert _rel(out, ref) < TOL[terms], (target, cin, cout)
+
+
+@pytest.mark.parametrize("terms", [2, 3])
+@pytest.mark.parametrize("target", [300, 1500, 12000])
+def test_f32_rows_with_split_products_equal_the_presplit_path(device, target, terms):
+    """m3d_conv_fwd_f32 at precision bf16x3 / bf16x6 gathers plain f32 rows into LDS and forms the terms after the
+    fragment read; m3d_conv_fwd_sf32 reads terms split beforehand.  Same terms, same products, same order: the
+    results are equal bit for bit (submanifold, two sources + epilogue + split output, strided, inverse, dense)."""
+    prec = PREC[terms]
+    sc = scenes.make_scene(seed=21, target_voxels=target)
+    off = np.array([0, sc["coord"].shape[0]], dtype=np.int64)
+    sp = oracle.sparsify(sc["coord"], sc["feat"], off, 0.02)
+    idx = torch.from_numpy(sp["voxel_coords"]).to(device)
+    n = idx.shape[0]
+    pair = ops.subm_rulebook(idx, sp["spatial_shape"])
+    sched = ops.build_schedule(pair, n, idx, 1, sp["spatial_shape"], 1)
+    oi, oshape, pf, pb = ops.strided_rulebook(idx, sp["spatial_shape"], 1)
+    m = oi.shape[0]
+    down, up = ops.build_schedule(pf, m, None, 0), ops.build_schedule(pb, n, None, 2, base_order=sched.out_row)
+    g = torch.Generator().manual_seed(target)
+    for cin, cout in [(32, 32), (96, 96), (64, 128), (256, 256)]:
+        x = torch.randn(n, cin, generator=g).to(device)
+        wref = torch.randn(cout, 3, 3, 3, cin, generator=g) / np.sqrt(9 * cin)
+        w = ops.pack_weight(wref, prec, device)
+        a = ops.conv_fwd(x, w, sched, n)
+        b = ops.conv_fwd(ops.split_f32(x, terms), w, sched, n)
+        assert torch.equal(a, b), (cin, cout)
+        assert _rel(a, oracle.subm_conv(x.cpu(), wref, pair.cpu().numpy())) < TOL[terms]
+    # two sources, affine + residual + ReLU, f32 and split outputs
+    xa, xb = torch.randn(n, 96, generator=g).to(device), torch.randn(n, 32, generator=g).to(device)
+    w = ops.pack_weight(torch.randn(96, 3, 3, 3, 128, generator=g) / np.sqrt(9 * 128), prec, device)
+    scale, shift = (torch.rand(96, generator=g) + 0.5).to(device), torch.randn(96, generator=g).to(device)
+    res = torch.randn(n, 96, generator=g).to(device)
+    a, asp = ops.conv_fwd(xa, w, sched, n, in1=xb, scale=scale, shift=shift, residual=res, relu=True, split_terms=terms)
+    b, bsp = ops.conv_fwd(ops.split_f32(xa, terms), w, sched, n, in1=ops.split_f32(xb, terms), scale=scale, shift=shift,
+                          residual=res, relu=True, split_terms=terms)
+    assert torch.equal(a, b) and torch.equal(asp.data, bsp.data)
+    # strided, inverse, dense
+    x = torch.randn(n, 64, generator=g).to(device)
+    w = ops.pack_weight(torch.randn(128, 2, 2, 2, 64, generator=g) / np.sqrt(8 * 64), prec, device)
+    assert torch.equal(ops.conv_fwd(x, w, down, m), ops.conv_fwd(ops.split_f32(x, terms), w, down, m))
+    y = torch.randn(m, 128, generator=g).to(device)
+    wi = ops.pack_weight(torch.randn(64, 2, 2, 2, 128, generator=g) / np.sqrt(128), prec, device)
+    assert torch.equal(ops.conv_fwd(y, wi, up, n), ops.conv_fwd(ops.split_f32(y, terms), wi, up, n))
+    w1 = ops.pack_weight(torch.randn(768, 1, 1, 1, 96, generator=g) / np.sqrt(96), prec, device)
+    x96 = torch.randn(n, 96, generator=g).to(device)
+    assert torch.equal(ops.conv_fwd(x96, w1, None, n), ops.conv_fwd(ops.split_f32(x96, terms), w1, None, n))
+

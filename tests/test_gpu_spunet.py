@@ -51,6 +51,12 @@ def test_engine_matches_oracle(device, case, prec):
         out = eng.predict(coord, feat, b["offset"], 0.02, fold_head=fold)
         agree = (out["pred"].cpu() == ref_pred).float().mean().item()
         assert agree >= 0.999, (fold, agree)
+    # labels and the 768-d features of one and the same pass (what the reference's prediction record holds)
+    both = eng.predict(coord, feat, b["offset"], 0.02, return_features=True)
+    assert _rel_rows(both["voxel_feat"], case["ref"]) < 1e-4
+    assert (both["pred"].cpu() == ref_pred).float().mean().item() >= 0.999
+    with pytest.raises(ValueError):
+        eng.predict(coord, feat, b["offset"], 0.02, fold_head=True, return_features=True)
 
 
 def test_module_path_matches_oracle(device, case):

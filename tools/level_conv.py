@@ -21,7 +21,9 @@ levels = eng.build_levels(vox["voxel_coords"], vox["spatial_shape"], 1)
 lv = levels[level]
 sched, N, n_in, k = {"s": (lv.subm, lv.n, lv.n, 27), "d": (lv.down, lv.n_next, lv.n, 8), "u": (lv.up, lv.n, lv.n_next, 8),
                      "h": (None, lv.n, lv.n, 1)}[kind]
-x = ops.split_f32(torch.randn(n_in, cin, device=dev), ops.TERMS[prec])
+x = torch.randn(n_in, cin, device=dev)
+if os.environ.get("F32IN", "0") == "0":  # F32IN=1: plain f32 rows (the split, if any, happens inside the kernel)
+    x = ops.split_f32(x, ops.TERMS[prec])
 w = ops.pack_weight(torch.randn(cout, k, cin) * 0.03, prec, dev)
 ref = None
 for plan in plans:
