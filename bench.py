@@ -30,11 +30,13 @@ PEAK_HBM_GBS = 8000.0
 # peak in algorithmic (f32-product) FLOP/s of the instruction each precision issues: the split paths spend
 # 3 (6) bf16 MFMA products per f32 product, plain bf16 one
 PEAK = {"f32": PEAK_F32_MFMA_TFLOPS, "bf16x6": PEAK_BF16_MFMA_TFLOPS / 6, "bf16x3": PEAK_BF16_MFMA_TFLOPS / 3,
-        "bf16": PEAK_BF16_MFMA_TFLOPS}
+        "bf16": PEAK_BF16_MFMA_TFLOPS, "f16x3": PEAK_BF16_MFMA_TFLOPS / 3}  # f16 and bf16 MFMA share one dense peak
 DTYPE = {"f32": "f32 (exact f32 MFMA)",
          "bf16x6": "f32 (every product: 6 bf16 MFMA products of 3-term splits, f32 accumulate; f32-level accuracy)",
          "bf16x3": "f32 storage, products from 2-term bf16 splits (3 bf16 MFMA products, f32 accumulate)",
-         "bf16": "bf16 storage, f32 accumulate"}
+         "bf16": "bf16 storage, f32 accumulate",
+         "f16x3": "f32 (every operand as an f16 pair exact to 2^-22: 3 f16 MFMA products, f32 accumulate; f32-level "
+                  "accuracy; operands must lie inside the f16 range, checked on the device)"}
 HEADLINE = "bf16x6"            # arithmetic not narrower than the reference's fp32 (see `parity` in the output)
 GRID = 0.02
 N_CLASSES = 200
@@ -144,7 +146,7 @@ def main():
     ap.add_argument("--target-voxels", type=int, default=TARGET_VOXELS)
     ap.add_argument("--scenes-per-rank", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--precision", default=HEADLINE, choices=["f32", "bf16x6", "bf16x3", "bf16"],
+    ap.add_argument("--precision", default=HEADLINE, choices=["f32", "bf16x6", "bf16x3", "bf16", "f16x3"],
                     help="how products are formed: exact f32 MFMA, bf16 MFMA on 3-/2-term splits of f32, plain bf16")
     ap.add_argument("--fold-head", action="store_true", help="fold `final` into the text matrix (not the headline)")
     ap.add_argument("--no-variants", action="store_true", help="skip the measurements of the other precisions")
@@ -227,7 +229,13 @@ def main():
         return time.perf_counter() - t0, nv
 
     with torch.no_grad():
+        if args.precision == "f16x3":
+            eng.f16_range_exceeded(clear=True)
         elapsed, nvox = timed(step, args.steps, args.warmup)
+        # precision f16x3: the timed passes count only if no operand left the f16 range (every rank checks its own)
+        f16_bad = bool(eng.f16_range_exceeded(clear=True)) if args.precision == "f16x3" else None
+        if f16_bad:
+            raise SystemExit("bench.py: an activation left the f16 range; precision f16x3 is not valid for this model")
 
         # convolution-kernel roofline: HIP events around every launch of a few more steps (this rank's stream)
         psteps = min(args.steps, 5)
@@ -244,14 +252,18 @@ def main():
         variants = {}
         engines = {args.precision: eng}
         if world == 1 and not args.no_variants and not args.fold_head:
-            for p in ("f32", "bf16x6", "bf16x3", "bf16"):
+            for p in ("f32", "bf16x6", "f16x3", "bf16x3", "bf16"):
                 if p == args.precision or p not in ops.PRECISION:
                     continue
                 e2, _, _ = build_engine(device, p)
                 engines[p] = e2
+                if p == "f16x3":
+                    e2.f16_range_exceeded(clear=True)
                 dt, nv = timed(lambda: step(e2, False), max(args.steps // 2, 3), 2)
                 steps_v = max(args.steps // 2, 3)
                 variants[p] = dict(ms_per_step=dt / steps_v * 1e3, voxels_per_s=nv / dt, dtype=DTYPE[p])
+                if p == "f16x3":  # the timed passes are valid only if no operand left the f16 range
+                    variants[p]["f16_range_exceeded"] = bool(e2.f16_range_exceeded(clear=True))
             dt, nv = timed(lambda: step(eng, True), max(args.steps // 2, 3), 2)
             variants["fold_head"] = dict(ms_per_step=dt / max(args.steps // 2, 3) * 1e3, voxels_per_s=nv / dt,
                                          note=f"{args.precision} with final 96->768 folded into the text matrix: same "
@@ -301,6 +313,8 @@ def main():
                     parity[p] = dict(feature_rel_err_max=mx, feature_rel_err_mean=mean,
                                      label_agreement=label_agreement(out["pred"], ref),
                                      voxel_order_and_maps="bit-exact")
+                    if p == "f16x3":  # no operand left the f16 range anywhere in this run (status word of the device)
+                        parity[p]["f16_range_exceeded"] = bool(ops.f16_status(clear=True))
             cb["label_agreement_vs_gpu"] = parity[args.precision]["label_agreement"]
         st = eng.last_stats
         wl = ("configs[1]: synthetic ScanNet-scale scene @2 cm, spunet34c+ppt forward + 768-d CLIP-text argmax "
@@ -316,6 +330,8 @@ def main():
                                 parallelism=f"scene-sharded x{world}, no collectives", fold_head=args.fold_head,
                                 precision=args.precision),
                     roofline=roofline, stages=stage_stats, cpu_baseline=cb, parity=parity, variants=variants or None)
+        if f16_bad is not None:
+            line["config"]["f16_range_exceeded"] = f16_bad
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

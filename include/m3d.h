@@ -36,6 +36,10 @@ extern "C" {
 #define M3D_PREC_BF16X3 1  /* f32 operands split in 2 bf16 terms, 3 bf16 MFMA products (~2^-17 per product) */
 #define M3D_PREC_BF16X6 2  /* f32 operands split in 3 bf16 terms, 6 bf16 MFMA products (~2^-24 per product) */
 #define M3D_PREC_BF16 3    /* operands rounded to bf16, one bf16 MFMA product, f32 accumulation (~2^-8 per product) */
+#define M3D_PREC_F16X3 4   /* f32 operands as an f16 pair (value = t0 + t1 * 2^-11, exact to 2^-22), 3 f16 MFMA products
+                              (~2^-21 per product); operands must lie inside the f16 range (|x| <= 65504): see
+                              m3d_f16_status.  Split-format code ("terms") of the pair: M3D_FMT_F16_PAIR */
+#define M3D_FMT_F16_PAIR 4
 
 #define M3D_HASH_FNV 0
 #define M3D_HASH_RAVEL 1
@@ -348,6 +352,13 @@ int m3d_halo_tile_rows(void);
 int m3d_build_halo(const int32_t* d_nbr, const int32_t* d_out_row, int k, int64_t npad, int64_t n_in,
                    int order_by_schedule, int32_t* d_halo_cnt, int32_t* d_halo_rows, uint16_t* d_halo_loc,
                    int32_t* d_halo_order, void* d_ws, size_t ws_bytes, void* stream);
+/* `terms` of the split-format entry points is 1, 2, 3 (bf16 terms) or M3D_FMT_F16_PAIR: [rows + 1][C/32][2][32] f16,
+ * term 0 = f16(x), term 1 = f16((x - term 0) * 2^11).
+ * m3d_f16_status: every kernel that writes the pair format sets a per-device status word when a value lies beyond
+ * the f16 range (or is NaN); *h_status receives it (0 = all values were representable; the call waits for the
+ * stream), `clear` != 0 resets it afterwards.  Results computed after a set status are not to be trusted: redo them
+ * with M3D_PREC_BF16X6.  No counterpart in the reference. */
+int m3d_f16_status(int* h_status, int clear, void* stream);
 size_t m3d_sf32_bytes(int64_t n, int c, int terms);
 int m3d_split_f32(const float* d_in, int64_t n, int c, int terms, void* d_out, void* stream);
 

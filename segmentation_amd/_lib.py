@@ -51,6 +51,7 @@ SIGNATURES = {
     "m3d_conv_bwd_weight_bf16x3": (_int, [_vp, _int, _vp, _int, _int, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _sz, _vp]),
     "m3d_bn_workspace_bytes": (_sz, [_i64, _int]),
     "m3d_bn_stats": (_int, [_vp, _i64, _int, _vp, _vp, _vp, _sz, _vp]),
+    "m3d_f16_status": (_int, [_vp, _int, _vp]),
     "m3d_bn_act_fwd": (_int, [_vp, _i64, _int, _vp, _vp, _f32, _vp, _vp, _vp, _int, _vp, _vp]),
     "m3d_bn_act_backward_reduce": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _vp, _vp, _vp, _sz, _vp]),
     "m3d_bn_act_backward": (_int, [_vp, _vp, _vp, _i64, _int, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -10,6 +10,7 @@
 namespace m3d {
 
 void set_error(const char* fmt, ...);
+int f16_status_ptr(int** out);  // conv.hip: device address of the f16 status word of the current device
 
 #define M3D_CHECK_ARG(cond, ...)            \
   do {                                      \

@@ -390,7 +390,7 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvArgs& a) {
   using G = DmaGeom<T>;                                                        // weight image
   // activation image: 16 f32 channels are 64 bytes (T = 3); 32 f32 channels are the 128 bytes of the two-term unit
   using GA = typename std::conditional<AF && T == 3, DmaGeomF32, DmaGeom<T>>::type;
-  static_assert(!AF || T == 3 || T == 2, "f32 activations: two- and three-term products only");
+  static_assert(!AF || T == 3 || T == 2 || T == kFmtF16, "f32 activations: two- and three-term products only");
   static_assert(GA::G == G::G && GA::UPS == G::UPS, "activation and weight units cover the same channels");
   constexpr int BM = 32 * WM, BN = 32 * NT * WN, NTHR = 64 * WM * WN;
   constexpr int A_BYTES = BM * GA::ROWB, W_BYTES = BN * G::ROWB, BUF = A_BYTES + W_BYTES;
@@ -434,7 +434,7 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvArgs& a) {
   }
   __syncthreads();
 
-  constexpr int NACC = T == 3 ? 2 : 1;
+  constexpr int NACC = (T == 3 || T == kFmtF16) ? 2 : 1;
   floatx16 acc[NACC][NT];
 #pragma unroll
   for (int c = 0; c < NACC; ++c)
@@ -580,6 +580,35 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvArgs& a) {
             const bf16x8 bf = *reinterpret_cast<const bf16x8*>(buf + w_off[nt][u * 2 + ks]);
             acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[0][nt], 0, 0, 0);
           }
+        }
+      }
+    } else if constexpr (T == kFmtF16) {
+      if (!m0) return;
+      // f16 pair: the two products with one (scaled) second term go to their own accumulator
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        halfx8 af[2];
+        if constexpr (AF) {
+          const float4 lo = *reinterpret_cast<const float4*>(buf + a_off[2 * ks]);
+          const float4 hi = *reinterpret_cast<const float4*>(buf + a_off[2 * ks + 1]);
+          const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            af[0][i] = (_Float16)v[i];
+            af[1][i] = (_Float16)((v[i] - (float)af[0][i]) * kF16Scale);
+          }
+        } else {
+#pragma unroll
+          for (int t = 0; t < 2; ++t) af[t] = *reinterpret_cast<const halfx8*>(buf + a_off[t * 2 + ks]);
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          halfx8 bf[2];
+#pragma unroll
+          for (int t = 0; t < 2; ++t) bf[t] = *reinterpret_cast<const halfx8*>(buf + w_off[nt][t * 2 + ks]);
+          acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0], bf[1], acc[1][nt], 0, 0, 0);
+          acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[1], bf[0], acc[1][nt], 0, 0, 0);
+          acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0], bf[0], acc[0][nt], 0, 0, 0);
         }
       }
     } else if constexpr (T == 2) {
@@ -733,7 +762,7 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvArgs& a) {
 #pragma unroll
     for (int i = 0; i < NT; ++i)
 #pragma unroll
-      for (int j = 0; j < 16; ++j) acc[0][i][j] += acc[1][i][j];
+      for (int j = 0; j < 16; ++j) acc[0][i][j] += T == kFmtF16 ? acc[1][i][j] * kF16Unscale : acc[1][i][j];
   }
   if (a.slab) {
     conv_epilogue<NT>(a, acc[0], orow_s, tile_base, col_base, wm, wn, lane);
@@ -749,12 +778,13 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_dma_kernel(ConvArgs a
 }
 
 // f32 [n][c] -> sf32 [n + 1][c/32][terms][32] bf16 (row n zero).  One thread per element.
-__global__ void split_f32_kernel(const float* __restrict__ in, int64_t n, int c, int terms, char* __restrict__ out) {
+__global__ void split_f32_kernel(const float* __restrict__ in, int64_t n, int c, int terms, char* __restrict__ out,
+                                 int* __restrict__ f16_status) {
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= (n + 1) * c) return;
   const int64_t row = e / c;
   const int col = (int)(e % c);
-  store_split(out, row, col, c, terms, row < n ? in[e] : 0.f);
+  store_split(out, row, col, c, terms, row < n ? in[e] : 0.f, f16_status);
 }
 
 // Reference layout [Cout][k][Cin] f32 -> kernel layouts.
@@ -765,7 +795,7 @@ __global__ void split_f32_kernel(const float* __restrict__ in, int64_t n, int c,
 // [cin'][kvol][cout'] of the layer it came from; cout/cin below are those of W'): the weight of the input-gradient
 // convolution, formed without a transposed copy of w.
 __global__ void pack_weight_kernel(const float* __restrict__ w, int cout, int kvol, int cin, int terms,
-                                   int transposed, int flip, void* __restrict__ out) {
+                                   int transposed, int flip, void* __restrict__ out, int* __restrict__ f16_status) {
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t total = (int64_t)cout * kvol * cin;
   if (e >= total) return;
@@ -779,7 +809,12 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, int cout, int kv
   }
   const int gs = split_group_shift(terms), g = 1 << gs;
   __bf16* dst = static_cast<__bf16*>(out) +
-                (((((int64_t)k * cout + o) * (cin >> gs) + (c >> gs)) * terms) << gs) + (c & (g - 1));
+                (((((int64_t)k * cout + o) * (cin >> gs) + (c >> gs)) * split_nterms(terms)) << gs) + (c & (g - 1));
+  if (terms == kFmtF16) {
+    float one[1] = {x};
+    split_store_n<1>(reinterpret_cast<char*>(dst), 2 * g, terms, one, f16_status);
+    return;
+  }
   for (int t = 0; t < terms; ++t) {
     const __bf16 q = (__bf16)x;
     dst[t * g] = q;
@@ -803,7 +838,7 @@ __global__ __launch_bounds__(256) void conv_reduce_kernel(ConvArgs a, int nz) {
   if (a.residual) v += a.residual[(int64_t)orow * a.cout + col];
   if (a.relu) v = fmaxf(v, 0.f);
   if (a.out) a.out[(int64_t)orow * a.ldo + col] = v;
-  if (a.out_split) store_split(a.out_split, orow, col, a.cout, a.terms, v);
+  if (a.out_split) store_split(a.out_split, orow, col, a.cout, a.terms, v, a.f16_status);
 }
 
 // Few input channels (the 3-channel stem): one thread per output row computes CO output channels; the
@@ -868,16 +903,11 @@ __global__ __launch_bounds__(256) void conv_rowwise_f32_kernel(ConvArgs a) {
     const int tstride = 2 << split_group_shift(a.terms);
 #pragma unroll
     for (int o8 = 0; o8 < CO / 8; ++o8) {
-      char* base = split_ptr(a.out_split, orow, co_base + o8 * 8, a.cout, a.terms);
-      for (int tt = 0; tt < a.terms; ++tt) {
-        bf16x8 q;
+      float v8[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          q[i] = (__bf16)v[o8 * 8 + i];
-          v[o8 * 8 + i] -= (float)q[i];
-        }
-        *reinterpret_cast<bf16x8*>(base + tt * tstride) = q;
-      }
+      for (int i = 0; i < 8; ++i) v8[i] = v[o8 * 8 + i];
+      split_store_n<8>(split_ptr(a.out_split, orow, co_base + o8 * 8, a.cout, a.terms), tstride, a.terms, v8,
+                       a.f16_status);
     }
   }
 }
@@ -917,7 +947,7 @@ __global__ __launch_bounds__(256) void conv_direct_f32_kernel(ConvArgs a) {
   if (a.residual) v += a.residual[(int64_t)orow * a.cout + col];
   if (a.relu) v = fmaxf(v, 0.f);
   if (a.out) a.out[(int64_t)orow * a.ldo + col] = v;
-  if (a.out_split) store_split(a.out_split, orow, col, a.cout, a.terms, v);
+  if (a.out_split) store_split(a.out_split, orow, col, a.cout, a.terms, v, a.f16_status);
 }
 
 template <int WM, int WN, int NT>
@@ -958,13 +988,16 @@ static int launch_dma_n(const ConvArgs& a, int nz, hipStream_t stream) {
   return M3D_OK;
 }
 
-// Zero bytes for the gathers of missing neighbours when the activations are plain f32 rows (one copy per device,
-// never written).
+// Per-device constants of the library: zero bytes for the gathers of missing neighbours when the activations are
+// plain f32 rows (never written), and the f16 status word (set to 1 by any kernel that writes a value beyond the
+// f16 range into the f16 pair format; read and cleared through m3d_f16_status).
 static __device__ __align__(256) char conv_zero_bytes[256];
+static __device__ int conv_f16_status_word;
 
-static int conv_zero_ptr(const char** out) {
+static int device_symbols(const char** zero, int** status) {
   static std::mutex mu;
-  static const char* ptr[64] = {};
+  static const char* zptr[64] = {};
+  static int* sptr[64] = {};
   int dev = 0;
   M3D_HIP(hipGetDevice(&dev));
   if (dev < 0 || dev >= 64) {
@@ -972,14 +1005,20 @@ static int conv_zero_ptr(const char** out) {
     return M3D_EINVAL;
   }
   std::lock_guard<std::mutex> lock(mu);
-  if (ptr[dev] == nullptr) {
+  if (zptr[dev] == nullptr) {
     void* p = nullptr;
     M3D_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(conv_zero_bytes)));
-    ptr[dev] = static_cast<const char*>(p);
+    void* q = nullptr;
+    M3D_HIP(hipGetSymbolAddress(&q, HIP_SYMBOL(conv_f16_status_word)));
+    zptr[dev] = static_cast<const char*>(p);
+    sptr[dev] = static_cast<int*>(q);
   }
-  *out = ptr[dev];
+  if (zero) *zero = zptr[dev];
+  if (status) *status = sptr[dev];
   return M3D_OK;
 }
+
+int f16_status_ptr(int** out) { return device_symbols(nullptr, out); }
 
 // Ring depth: two buffers everywhere.  A third (which the 96-byte rows of the three-term format leave room for at two
 // workgroups per CU) measured 4 % slower on the largest level: the stage loop is bound by the issue of its DMA
@@ -1055,12 +1094,13 @@ extern "C" size_t m3d_conv_workspace_bytes(int64_t n, int cout, int k) {
 }
 
 // mode: 0 exact f32; 1/2/5 bf16 products with the f32 activations split inside the kernel (T = 2/3/1);
-// 3/4/6 LDS-DMA on sf32 inputs (T = 2/3/1); 7/8 LDS-DMA on f32 inputs, terms formed after the fragment read (T = 3/2)
+// 3/4/6/9 LDS-DMA on sf32 inputs (T = 2/3/1/f16 pair); 7/8/10 LDS-DMA on f32 inputs, terms formed after the fragment
+// read (T = 3/2/f16 pair)
 static int run_conv(ConvArgs& a, int mode, bool mfma_ok, void* d_ws, size_t ws_bytes, hipStream_t stream,
                     const char* who) {
   a.slab = nullptr;
   if (!mfma_ok) {
-    if (mode == 3 || mode == 4 || mode == 6) {
+    if (mode == 3 || mode == 4 || mode == 6 || mode >= 7) {
       set_error("%s: channel counts must be multiples of 32", who);
       return M3D_EINVAL;
     }
@@ -1085,7 +1125,7 @@ static int run_conv(ConvArgs& a, int mode, bool mfma_ok, void* d_ws, size_t ws_b
         a.cout % (32 * q.nt * q.wn) == 0 && a.npad % (32 * q.wm) == 0 && q.nz >= 1 && q.nz <= a.kvol)
       p = q;
   }
-  const bool dma = mode == 3 || mode == 4 || mode == 6 || mode == 7 || mode == 8;
+  const bool dma = mode == 3 || mode == 4 || mode == 6 || mode >= 7;
   if (dma && p.wm == 1 && p.wn == 3) p = ConvPlan{1, 1, 3, p.nz};  // equal DMA count per wave
   if (p.nz > 1) {
     const size_t need = (size_t)p.nz * a.npad * a.cout * sizeof(float);
@@ -1110,6 +1150,8 @@ static int run_conv(ConvArgs& a, int mode, bool mfma_ok, void* d_ws, size_t ws_b
     else if (mode == 6) rc = launch_dma<WM_, WN_, NT_, 1>(a, p.nz, stream);         \
     else if (mode == 7) rc = launch_dma_n<WM_, WN_, NT_, 3, 2, true>(a, p.nz, stream); \
     else if (mode == 8) rc = launch_dma_n<WM_, WN_, NT_, 2, 2, true>(a, p.nz, stream); \
+    else if (mode == 9) rc = launch_dma_n<WM_, WN_, NT_, kFmtF16, 2, false>(a, p.nz, stream); \
+    else if (mode == 10) rc = launch_dma_n<WM_, WN_, NT_, kFmtF16, 2, true>(a, p.nz, stream); \
   }
   if (!dma) {
     M3D_CASE(4, 1, 1) M3D_CASE(4, 1, 2) M3D_CASE(4, 1, 3) M3D_CASE(4, 1, 4)
@@ -1175,9 +1217,9 @@ extern "C" int m3d_conv_fwd_f32(const float* d_in0, int c0, const float* d_in1, 
   M3D_CHECK_ARG(c0 > 0 && c1 >= 0 && cout > 0 && k >= 1 && k <= 27, "%s: bad channel/kernel sizes", who);
   M3D_CHECK_ARG((c1 == 0) == (d_in1 == nullptr), "%s: in1/c1 mismatch", who);
   M3D_CHECK_ARG(d_out == nullptr || ldo >= cout, "%s: ldo < cout", who);
-  M3D_CHECK_ARG(precision >= 0 && precision <= 3, "%s: unknown precision %d", who, precision);
-  M3D_CHECK_ARG(d_out_split == nullptr || (out_terms >= 1 && out_terms <= 3 && cout % 32 == 0),
-                "%s: a split output needs out_terms in {1,2,3} and cout %% 32 == 0", who);
+  M3D_CHECK_ARG(precision >= 0 && precision <= M3D_PREC_F16X3, "%s: unknown precision %d", who, precision);
+  M3D_CHECK_ARG(d_out_split == nullptr || (out_terms >= 1 && out_terms <= kFmtF16 && cout % 32 == 0),
+                "%s: a split output needs out_terms in {1,2,3,4} and cout %% 32 == 0", who);
   if (int rc = check_schedule(d_nbr, d_out_row, d_tile_mask, k, n, &npad, who)) return rc;
   ConvArgs a = {};
   a.in0 = d_in0; a.in1 = d_in1; a.weight = d_weight; a.nbr = d_nbr; a.out_row = d_out_row;
@@ -1191,7 +1233,14 @@ extern "C" int m3d_conv_fwd_f32(const float* d_in0, int c0, const float* d_in1, 
   // slabs whose sum is a multiple of 32 but which are not multiples themselves have no kernel
   M3D_CHECK_ARG(precision == M3D_PREC_F32 || mfma_ok || (c0 + c1) % 32 != 0 || cout % 32 != 0,
                 "%s: with a bf16 precision both input slabs (%d, %d) must be multiples of 32 channels", who, c0, c1);
+  if (int rc = device_symbols(&a.zbuf, &a.f16_status)) return rc;
   int mode = precision == M3D_PREC_BF16 ? 5 : precision;
+  if (precision == M3D_PREC_F16X3) {
+    // the f16 pair has no kernel outside the matrix-core path: small layers (the stem) run in exact f32
+    mode = mfma_ok ? 10 : 0;
+    a.s0 = reinterpret_cast<const char*>(d_in0);
+    a.s1 = reinterpret_cast<const char*>(d_in1);
+  }
   // split products: the f32 rows go to LDS as they are (M3D_F32_DMA=0: split in registers on the way to LDS)
   static const bool f32_dma = [] {
     const char* e = getenv("M3D_F32_DMA");
@@ -1201,7 +1250,6 @@ extern "C" int m3d_conv_fwd_f32(const float* d_in0, int c0, const float* d_in1, 
     mode = mode == 2 ? 7 : 8;
     a.s0 = reinterpret_cast<const char*>(d_in0);
     a.s1 = reinterpret_cast<const char*>(d_in1);
-    if (int rc = conv_zero_ptr(&a.zbuf)) return rc;
   }
   return run_conv(a, mode, mfma_ok, d_ws, ws_bytes, stream, who);
 }
@@ -1219,7 +1267,7 @@ extern "C" int m3d_conv_fwd_sf32(const void* d_in0, int c0, int64_t rows0, const
   M3D_CHECK_ARG(n >= 0, "%s: n < 0", who);
   if (n == 0) return M3D_OK;
   M3D_CHECK_ARG(d_in0 && d_weight && (d_out || d_out_split), "%s: null pointer", who);
-  M3D_CHECK_ARG(terms >= 1 && terms <= 3, "%s: terms must be 1, 2 or 3", who);
+  M3D_CHECK_ARG(terms >= 1 && terms <= kFmtF16, "%s: terms must be 1, 2, 3 or 4 (the f16 pair)", who);
   M3D_CHECK_ARG(c0 > 0 && c1 >= 0 && cout > 0 && k >= 1 && k <= 27, "%s: bad channel/kernel sizes", who);
   M3D_CHECK_ARG(c0 % 32 == 0 && c1 % 32 == 0 && cout % 32 == 0, "%s: channel counts must be multiples of 32", who);
   M3D_CHECK_ARG((c1 == 0) == (d_in1 == nullptr), "%s: in1/c1 mismatch", who);
@@ -1242,20 +1290,35 @@ extern "C" int m3d_conv_fwd_sf32(const void* d_in0, int c0, int64_t rows0, const
     return run_conv_halo(a, d_halo_cnt, d_halo_rows, d_halo_loc, d_halo_order, stream);
   }
   a.tile_order = d_tile_order;
-  return run_conv(a, terms == 2 ? 3 : (terms == 3 ? 4 : 6), true, d_ws, ws_bytes, stream, who);
+  if (int rc = device_symbols(&a.zbuf, &a.f16_status)) return rc;
+  return run_conv(a, terms == 2 ? 3 : (terms == 3 ? 4 : (terms == kFmtF16 ? 9 : 6)), true, d_ws, ws_bytes, stream, who);
+}
+
+extern "C" int m3d_f16_status(int* h_status, int clear, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  int* status = nullptr;
+  if (int rc = device_symbols(nullptr, &status)) return rc;
+  if (h_status) {
+    M3D_HIP(hipMemcpyAsync(h_status, status, sizeof(int), hipMemcpyDeviceToHost, stream));
+    M3D_HIP(hipStreamSynchronize(stream));
+  }
+  if (clear) M3D_HIP(hipMemsetAsync(status, 0, sizeof(int), stream));
+  return M3D_OK;
 }
 
 extern "C" size_t m3d_sf32_bytes(int64_t n, int c, int terms) {
-  return (size_t)(n + 1) * (size_t)c * 2 * (size_t)terms;
+  return (size_t)(n + 1) * (size_t)c * 2 * (size_t)split_nterms(terms);
 }
 
 extern "C" int m3d_split_f32(const float* d_in, int64_t n, int c, int terms, void* d_out, void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
-  M3D_CHECK_ARG(d_in && d_out && n >= 0 && c > 0 && c % 32 == 0 && terms >= 1 && terms <= 3,
+  M3D_CHECK_ARG(d_in && d_out && n >= 0 && c > 0 && c % 32 == 0 && terms >= 1 && terms <= kFmtF16,
                 "m3d_split_f32: bad arguments");
+  int* status = nullptr;
+  if (int rc = device_symbols(nullptr, &status)) return rc;
   const int64_t total = (n + 1) * c;
   hipLaunchKernelGGL(split_f32_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, stream, d_in, n, c, terms,
-                     static_cast<char*>(d_out));
+                     static_cast<char*>(d_out), status);
   M3D_LAUNCH_CHECK();
   return M3D_OK;
 }
@@ -1264,20 +1327,23 @@ extern "C" size_t m3d_conv_packed_weight_bytes(int cout, int k, int cin, int pre
   const bool mfma_ok = cin % 32 == 0 && cout % 32 == 0;
   const size_t elems = (size_t)cout * k * cin;
   if (precision == M3D_PREC_F32 || !mfma_ok) return elems * sizeof(float);
-  return elems * 2 * (precision == M3D_PREC_BF16X3 ? 2 : (precision == M3D_PREC_BF16X6 ? 3 : 1));
+  return elems * 2 * (precision == M3D_PREC_BF16X3 || precision == M3D_PREC_F16X3 ? 2 : (precision == M3D_PREC_BF16X6 ? 3 : 1));
 }
 
 static int pack_weight_launch(const char* who, const float* d_weight_ref, int cout, int k, int cin, int precision,
                               int transposed, int flip, void* d_out, void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   M3D_CHECK_ARG(d_weight_ref && d_out && cout > 0 && k > 0 && cin > 0, "%s: bad arguments", who);
-  M3D_CHECK_ARG(precision >= 0 && precision <= 3, "%s: unknown precision %d", who, precision);
+  M3D_CHECK_ARG(precision >= 0 && precision <= M3D_PREC_F16X3, "%s: unknown precision %d", who, precision);
   const bool mfma_ok = cin % 32 == 0 && cout % 32 == 0;
   const int terms = (precision == M3D_PREC_F32 || !mfma_ok) ? 0
-                    : (precision == M3D_PREC_BF16X3 ? 2 : (precision == M3D_PREC_BF16X6 ? 3 : 1));
+                    : (precision == M3D_PREC_BF16X3 ? 2 : (precision == M3D_PREC_BF16X6 ? 3
+                    : (precision == M3D_PREC_F16X3 ? kFmtF16 : 1)));
+  int* status = nullptr;
+  if (int rc = device_symbols(nullptr, &status)) return rc;
   const int64_t total = (int64_t)cout * k * cin;
   hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, stream, d_weight_ref,
-                     cout, k, cin, terms, transposed, flip, d_out);
+                     cout, k, cin, terms, transposed, flip, d_out, status);
   M3D_LAUNCH_CHECK();
   return M3D_OK;
 }

@@ -29,38 +29,93 @@ struct ConvArgs {
   int terms;             // T of out_split
   const int32_t* tile_order;  // optional: tile taken by workgroup blockIdx.x of a 128-row-tile launch
   const char* zbuf;           // >= 64 zero bytes: what a missing neighbour gathers when s0 / s1 are plain f32 rows
+  int* f16_status;            // set to 1 when a value written in the f16 pair format is beyond the f16 range
 };
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 halfx8 __attribute__((ext_vector_type(8)));
+typedef _Float16 halfx4 __attribute__((ext_vector_type(4)));
 
 // Split format ("sf32") of an [rows, c] tensor with T terms: [rows + 1][c/G][T][G] bf16, G = 16 channels per group
 // for T = 3 and 32 otherwise (T = 1 is plain row-major bf16); term t = bf16 rounding of what the earlier terms left
 // over; row `rows` is all zero.  split_group_shift(T) = log2 G; split_ptr = address of term 0 of (row, col), the other
 // terms follow at a stride of 2 G bytes.
+//
+// `terms` doubles as the format code: 1, 2, 3 = that many bf16 terms; kFmtF16 (4) = the f16 pair: two f16 terms in
+// the geometry of two bf16 terms, term 0 = f16 rounding of the value, term 1 = f16 rounding of (value - term 0) * 2^11
+// (the scale keeps the second term out of the f16 subnormals; products with one second term are accumulated
+// apart and scaled back by 2^-11).  An operand is then exact to 2^-22 of its value, and a value beyond the f16
+// range (65504) raises the library's f16 status word instead of going unnoticed.
+constexpr int kFmtF16 = 4;
+constexpr float kF16Scale = 2048.f, kF16Unscale = 1.f / 2048.f, kF16Max = 65504.f;
+__host__ __device__ inline int split_nterms(int fmt) { return fmt == kFmtF16 ? 2 : fmt; }
 __host__ __device__ inline int split_group_shift(int terms) { return terms == 3 ? 4 : 5; }
 
 __device__ inline char* split_ptr(char* base, int64_t row, int col, int c, int terms) {
   const int gs = split_group_shift(terms);
-  return base + (((row * (c >> gs) + (col >> gs)) * terms) << (gs + 1)) + ((col & ((1 << gs) - 1)) << 1);
+  return base + (((row * (c >> gs) + (col >> gs)) * split_nterms(terms)) << (gs + 1)) + ((col & ((1 << gs) - 1)) << 1);
+}
+
+// All terms of N consecutive channels (N = 1, 4 or 8; same group) of one row: term t goes to base + t * tstride.
+template <int N>
+__device__ inline void split_store_n(char* base, int tstride, int fmt, float (&v)[N], int* f16_status) {
+  if (fmt == kFmtF16) {
+    typedef _Float16 hN __attribute__((ext_vector_type(N)));
+    _Float16 q0[N], q1[N];
+    bool over = false;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      over |= !(fabsf(v[i]) <= kF16Max);  // also true for NaN
+      q0[i] = (_Float16)v[i];
+      q1[i] = (_Float16)((v[i] - (float)q0[i]) * kF16Scale);
+    }
+    if (over && f16_status) *f16_status = 1;
+    if constexpr (N == 1) {
+      *reinterpret_cast<_Float16*>(base) = q0[0];
+      *reinterpret_cast<_Float16*>(base + tstride) = q1[0];
+    } else {
+      hN w0, w1;
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        w0[i] = q0[i];
+        w1[i] = q1[i];
+      }
+      *reinterpret_cast<hN*>(base) = w0;
+      *reinterpret_cast<hN*>(base + tstride) = w1;
+    }
+    return;
+  }
+  for (int t = 0; t < fmt; ++t) {
+    if constexpr (N == 1) {
+      const __bf16 q = (__bf16)v[0];
+      *reinterpret_cast<__bf16*>(base + t * tstride) = q;
+      v[0] -= (float)q;
+    } else {
+      typedef __bf16 bN __attribute__((ext_vector_type(N)));
+      bN q;
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        q[i] = (__bf16)v[i];
+        v[i] -= (float)q[i];
+      }
+      *reinterpret_cast<bN*>(base + t * tstride) = q;
+    }
+  }
 }
 
 // One element of an sf32 tensor.
-__device__ inline void store_split(char* base, int64_t row, int col, int c, int terms, float v) {
-  __bf16* p = reinterpret_cast<__bf16*>(split_ptr(base, row, col, c, terms));
-  const int g = 1 << split_group_shift(terms);
-  for (int t = 0; t < terms; ++t) {
-    const __bf16 q = (__bf16)v;
-    p[t * g] = q;
-    v -= (float)q;
-  }
+__device__ inline void store_split(char* base, int64_t row, int col, int c, int terms, float v, int* f16_status = nullptr) {
+  float one[1] = {v};
+  split_store_n<1>(split_ptr(base, row, col, c, terms), 2 << split_group_shift(terms), terms, one, f16_status);
 }
 
 // The all-zero row (index n) of an sf32 output; called by one workgroup of the kernel that writes the output.
 __device__ inline void clear_zero_row(const ConvArgs& a) {
   if (a.out_split == nullptr) return;
-  const int words = a.cout * a.terms / 2;  // 4-byte words in one row
-  uint32_t* p = reinterpret_cast<uint32_t*>(a.out_split + (int64_t)a.n * a.cout * a.terms * 2);
+  const int nt = split_nterms(a.terms);
+  const int words = a.cout * nt / 2;  // 4-byte words in one row
+  uint32_t* p = reinterpret_cast<uint32_t*>(a.out_split + (int64_t)a.n * a.cout * nt * 2);
   for (int i = threadIdx.x; i < words; i += blockDim.x) p[i] = 0u;
 }
 
@@ -97,7 +152,7 @@ __device__ inline void conv_epilogue(const ConvArgs& a, const floatx16 (&acc)[NT
         if (a.residual) v += a.residual[(int64_t)orow * a.cout + col];
         if (a.relu) v = fmaxf(v, 0.f);
         if (a.out) a.out[(int64_t)orow * a.ldo + col] = v;
-        if (a.out_split) store_split(a.out_split, orow, col, a.cout, a.terms, v);
+        if (a.out_split) store_split(a.out_split, orow, col, a.cout, a.terms, v, a.f16_status);
       }
     }
   }
@@ -147,17 +202,8 @@ __device__ inline void conv_store_tile(const ConvArgs& a, const float* S, const 
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], 0.f);
       }
-      char* base = split_ptr(a.out_split, orow, col, a.cout, a.terms);
-      const int tstride = 2 << split_group_shift(a.terms);
-      for (int t = 0; t < a.terms; ++t) {
-        bf16x8 q;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          q[i] = (__bf16)v[i];
-          v[i] -= (float)q[i];
-        }
-        *reinterpret_cast<bf16x8*>(base + t * tstride) = q;
-      }
+      split_store_n<8>(split_ptr(a.out_split, orow, col, a.cout, a.terms), 2 << split_group_shift(a.terms), a.terms, v,
+                       a.f16_status);
     }
     return;
   }
@@ -186,19 +232,9 @@ __device__ inline void conv_store_tile(const ConvArgs& a, const float* S, const 
         for (int i = 0; i < 4; ++i) o[i] = v[i];
       }
     }
-    if (a.out_split) {
-      char* base = split_ptr(a.out_split, orow, col, a.cout, a.terms);
-      const int tstride = 2 << split_group_shift(a.terms);
-      for (int t = 0; t < a.terms; ++t) {
-        bf16x4 q;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          q[i] = (__bf16)v[i];
-          v[i] -= (float)q[i];
-        }
-        *reinterpret_cast<bf16x4*>(base + t * tstride) = q;
-      }
-    }
+    if (a.out_split)
+      split_store_n<4>(split_ptr(a.out_split, orow, col, a.cout, a.terms), 2 << split_group_shift(a.terms), a.terms, v,
+                       a.f16_status);
   }
 }
 
@@ -262,11 +298,12 @@ constexpr int kLdr = 36;  // LDS row stride in floats
 // whose rows cover every residue mod 16; with 128-byte rows two rows share a 256-byte bank line and the eight
 // row pairs take the eight XOR patterns; with 96-byte rows the rows r and r + 8 start on the same banks and take
 // the two slots of a piece pair.
+// T = kFmtF16 (the f16 pair) has the geometry of T = 2.
 template <int T>
 struct DmaGeom {
   static constexpr int G = T == 3 ? 16 : 32;   // channels per unit
   static constexpr int UPS = T == 1 ? 2 : 1;   // units per stage
-  static constexpr int PIECES = T == 1 ? 4 : (T == 2 ? 8 : 6);
+  static constexpr int PIECES = T == 1 ? 4 : (T == 3 ? 6 : 8);
   static constexpr int SLOTS = T == 3 ? 6 : 8;
   static constexpr int ROWB = SLOTS * 16;
   __device__ static inline int swz(int r) { return T == 3 ? ((r >> 3) & 1) : ((r >> 1) & 7); }

@@ -37,6 +37,7 @@ struct HeadArgs {
   int64_t n;
   int cmid, n_classes;
   int full_blocks, tail_waves;  // workgroups below full_blocks take 32 * NW rows, the others 32 * tail_waves
+  int* f16_status;              // f16 pair kernels: set when a feature leaves the f16 range
 };
 
 constexpr int kHeadMaxFeatures = 1024;  // cmid limit of the fused kernel (scale/shift staging)
@@ -61,7 +62,28 @@ __global__ void head_pack_text_kernel(const float* __restrict__ text, int n_clas
   dst[32] = (__bf16)(v - (float)hi);
 }
 
+// The same for the f16 pair kernel: [classes_padded][cmid/32][2][32] f16, second term NOT scaled (the logits only
+// feed the argmax and take one accumulator; text rows are unit vectors, far inside the f16 range)
+__global__ void head_pack_text_f16_kernel(const float* __restrict__ text, int n_classes, int cmid, int classes_padded,
+                                          _Float16* __restrict__ out) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (int64_t)classes_padded * cmid) return;
+  const int j = (int)(e / cmid), q = (int)(e % cmid);
+  const int grp = q >> 5, p = q & 31;
+  float v = j < n_classes ? text[(int64_t)j * cmid + grp * 32 + head_perm_channel(p)] : 0.f;
+  _Float16* dst = out + ((int64_t)j * (cmid >> 5) + grp) * 64 + p;
+  const _Float16 hi = (_Float16)v;
+  dst[0] = hi;
+  dst[32] = (_Float16)(v - (float)hi);
+}
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <bool F16, class V>
+__device__ __forceinline__ floatx16 head_mfma(const V& a, const V& b, const floatx16& c) {
+  if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
 
 // LDS read issued outside the compiler's view (it neither schedules it late nor guards it with a wait on the
 // LDS-DMA traffic); the value is only valid after an s_waitcnt that lists the destination as an operand.
@@ -79,9 +101,13 @@ __device__ __forceinline__ void static_for(F&& f) {
   }
 }
 
-template <int G1, int NT2, int NW>
+// F16: operands are f16 pairs.  x and W1 carry the scaled second term of the convolution format (x 2^11), so the
+// features accumulate leading and second-term products apart; the feature tile and the text matrix are split without
+// the scale and the logits take one accumulator.
+template <int G1, int NT2, int NW, bool F16>
 __device__ __forceinline__ void head_fused_body(const HeadArgs& a) {
   using G = DmaGeom<2>;
+  using V8 = typename std::conditional<F16, halfx8, bf16x8>::type;
   constexpr int NBUF = 3, NTHR = 64 * NW, ROWS = 32 * NW;
   constexpr int W1_BYTES = 32 * G1 * G::ROWB, W2_BYTES = NT2 * 32 * G::ROWB, BUF = W1_BYTES + W2_BYTES;
   constexpr int W1_SLOTS = 32 * G1 * G::SLOTS, SLOTS = W1_SLOTS + NT2 * 32 * G::SLOTS;
@@ -104,7 +130,7 @@ __device__ __forceinline__ void head_fused_body(const HeadArgs& a) {
   const int nstage = a.cmid >> 5;
 
   // activation fragments of this wave's 32 rows (rows past the end read the zero row)
-  bf16x8 xf[G1][2][2];
+  V8 xf[G1][2][2];
   {
     const int64_t row = tile_base + wave * 32 + r32;
     const char* xp = a.x + (active && row < a.n ? row : a.n) * (int64_t)(G1 * G::ROWB);
@@ -114,7 +140,7 @@ __device__ __forceinline__ void head_fused_body(const HeadArgs& a) {
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
         for (int t = 0; t < 2; ++t)
-          xf[g][ks][t] = *reinterpret_cast<const bf16x8*>(xp + g * G::ROWB + t * 64 + (ks * 2 + h) * 16);
+          xf[g][ks][t] = *reinterpret_cast<const V8*>(xp + g * G::ROWB + t * 64 + (ks * 2 + h) * 16);
   }
   for (int i = tid; i < a.cmid; i += NTHR) {
     aff_s[i] = a.scale ? a.scale[i] : 1.f;
@@ -172,7 +198,7 @@ __device__ __forceinline__ void head_fused_body(const HeadArgs& a) {
   auto fragment_pipeline = [&](auto nsteps_c, auto base_off_c, uint32_t sbuf, auto&& body) {
     constexpr int NSTEPS = decltype(nsteps_c)::value, BASE = decltype(base_off_c)::value;
     const uint32_t p00 = sbuf + frag[0][0], p01 = sbuf + frag[0][1], p10 = sbuf + frag[1][0], p11 = sbuf + frag[1][1];
-    bf16x8 bh[3], bl[3];
+    V8 bh[3], bl[3];
     auto request = [&](auto ic) {
       constexpr int i = decltype(ic)::value;
       if constexpr (i < NSTEPS) {
@@ -198,7 +224,7 @@ __device__ __forceinline__ void head_fused_body(const HeadArgs& a) {
     });
   };
 
-  bf16x8 ah[2], al[2];  // the current feature tile as A operand: [reduction half] hi / lo terms
+  V8 ah[2], al[2];  // the current feature tile as A operand: [reduction half] hi / lo terms
 
   // A(s): F^T tile of features 32 s .. 32 s + 31 (features x rows), affine, split into ah / al
   const bool has_scale = a.scale != nullptr;
@@ -219,13 +245,27 @@ __device__ __forceinline__ void head_fused_body(const HeadArgs& a) {
 #pragma unroll
       for (int j = 0; j < 16; ++j) f[j] = sh[j >> 2][j & 3];
     }
+    floatx16 fs;  // F16: products with one scaled second term
+    if constexpr (F16) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) fs[j] = 0.f;
+    }
     fragment_pipeline(std::integral_constant<int, 2 * G1>{}, std::integral_constant<int, 0>{},
-                      lds_base + (uint32_t)((s % NBUF) * BUF), [&](auto ic, const bf16x8& wh, const bf16x8& wl) {
+                      lds_base + (uint32_t)((s % NBUF) * BUF), [&](auto ic, const V8& wh, const V8& wl) {
                         constexpr int i = decltype(ic)::value, g = i >> 1, ks = i & 1;
-                        f = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, xf[g][ks][0], f, 0, 0, 0);
-                        f = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xf[g][ks][1], f, 0, 0, 0);
-                        f = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xf[g][ks][0], f, 0, 0, 0);
+                        if constexpr (F16) {
+                          fs = head_mfma<F16>(wl, xf[g][ks][0], fs);
+                          fs = head_mfma<F16>(wh, xf[g][ks][1], fs);
+                        } else {
+                          f = head_mfma<F16>(wl, xf[g][ks][0], f);
+                          f = head_mfma<F16>(wh, xf[g][ks][1], f);
+                        }
+                        f = head_mfma<F16>(wh, xf[g][ks][0], f);
                       });
+    if constexpr (F16) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) f[j] += fs[j] * kF16Unscale;
+    }
     if (has_scale) {
       static_for<0, 4>([&](auto qc) {
         constexpr int q = decltype(qc)::value;
@@ -237,22 +277,35 @@ __device__ __forceinline__ void head_fused_body(const HeadArgs& a) {
         for (int i = 0; i < 4; ++i) f[4 * q + i] = f[4 * q + i] * sc[i] + sh[i];
       });
     }
+    if constexpr (F16) {
+      bool over = false;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {  // split into the A operand of the second product
-      const float v = f[j];
-      const __bf16 hi = (__bf16)v;
-      ah[j >> 3][j & 7] = hi;
-      al[j >> 3][j & 7] = (__bf16)(v - (float)hi);
+      for (int j = 0; j < 16; ++j) {  // split into the A operand of the second product (second term not scaled)
+        const float v = f[j];
+        over |= !(fabsf(v) <= kF16Max);
+        const _Float16 hi = (_Float16)v;
+        ah[j >> 3][j & 7] = hi;
+        al[j >> 3][j & 7] = (_Float16)(v - (float)hi);
+      }
+      if (over && a.f16_status) *a.f16_status = 1;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {  // split into the A operand of the second product
+        const float v = f[j];
+        const __bf16 hi = (__bf16)v;
+        ah[j >> 3][j & 7] = hi;
+        al[j >> 3][j & 7] = (__bf16)(v - (float)hi);
+      }
     }
   };
   // B(s): logits += F tile . W2 tile s
   auto stage_b = [&](int s) {
     fragment_pipeline(std::integral_constant<int, 2 * NT2>{}, std::integral_constant<int, W1_BYTES>{},
-                      lds_base + (uint32_t)((s % NBUF) * BUF), [&](auto ic, const bf16x8& bh, const bf16x8& bl) {
+                      lds_base + (uint32_t)((s % NBUF) * BUF), [&](auto ic, const V8& bh, const V8& bl) {
                         constexpr int i = decltype(ic)::value, nt = i >> 1, ks = i & 1;
-                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks], bl, acc[nt], 0, 0, 0);
-                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ks], bh, acc[nt], 0, 0, 0);
-                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks], bh, acc[nt], 0, 0, 0);
+                        acc[nt] = head_mfma<F16>(ah[ks], bl, acc[nt]);
+                        acc[nt] = head_mfma<F16>(al[ks], bh, acc[nt]);
+                        acc[nt] = head_mfma<F16>(ah[ks], bh, acc[nt]);
                       });
   };
 
@@ -319,17 +372,17 @@ __device__ __forceinline__ void head_fused_body(const HeadArgs& a) {
   }
 }
 
-template <int G1, int NT2, int NW>
+template <int G1, int NT2, int NW, bool F16 = false>
 __global__ __launch_bounds__(64 * NW) void head_fused_kernel(HeadArgs a) {
-  head_fused_body<G1, NT2, NW>(a);
+  head_fused_body<G1, NT2, NW, F16>(a);
 }
 
-template <int G1, int NT2, int NW>
+template <int G1, int NT2, int NW, bool F16 = false>
 static int launch_head(const HeadArgs& a, hipStream_t stream) {
   constexpr int BUF = (32 * G1 + 32 * NT2) * DmaGeom<2>::ROWB;
   const size_t lds = 3 * (size_t)BUF;
   static LdsGrant grant;
-  if (int rc = grant.ensure(reinterpret_cast<const void*>(&head_fused_kernel<G1, NT2, NW>), lds)) return rc;
+  if (int rc = grant.ensure(reinterpret_cast<const void*>(&head_fused_kernel<G1, NT2, NW, F16>), lds)) return rc;
   // rounds of one workgroup per CU; what is left after the full rounds goes out in pieces small enough for one round
   static const int ncu = [] {
     int dev = 0, v = 0;
@@ -348,8 +401,8 @@ static int launch_head(const HeadArgs& a, hipStream_t stream) {
     if (k < NW) b.tail_waves = (int)k;
   }
   const int64_t tail_blocks = rest > 0 ? cdiv(rest, (int64_t)32 * b.tail_waves) : 0;
-  hipLaunchKernelGGL((head_fused_kernel<G1, NT2, NW>), dim3((unsigned)(b.full_blocks + tail_blocks)), dim3(64 * NW), lds,
-                     stream, b);
+  hipLaunchKernelGGL((head_fused_kernel<G1, NT2, NW, F16>), dim3((unsigned)(b.full_blocks + tail_blocks)), dim3(64 * NW),
+                     lds, stream, b);
   M3D_LAUNCH_CHECK();
   return M3D_OK;
 }
@@ -597,8 +650,8 @@ __global__ void head_pack_text3_kernel(const float* __restrict__ text, int n_cla
 using namespace m3d;
 
 extern "C" size_t m3d_head_text_bytes_terms(int classes_padded, int cmid, int terms) {
-  if (classes_padded <= 0 || cmid <= 0 || (terms != 2 && terms != 3)) return 0;
-  return (size_t)classes_padded * cmid * terms * sizeof(__bf16);
+  if (classes_padded <= 0 || cmid <= 0 || (terms != 2 && terms != 3 && terms != kFmtF16)) return 0;
+  return (size_t)classes_padded * cmid * split_nterms(terms) * sizeof(__bf16);
 }
 
 extern "C" size_t m3d_head_text_bytes(int classes_padded, int cmid) {
@@ -622,21 +675,27 @@ extern "C" int m3d_head_pack_text_terms(const float* d_text, int n_classes, int 
                                         void* d_out, void* stream_) {
   if (terms == 2) return m3d_head_pack_text(d_text, n_classes, cmid, classes_padded, d_out, stream_);
   hipStream_t stream = static_cast<hipStream_t>(stream_);
-  M3D_CHECK_ARG(terms == 3, "m3d_head_pack_text_terms: terms must be 2 or 3");
+  M3D_CHECK_ARG(terms == 3 || terms == kFmtF16, "m3d_head_pack_text_terms: terms must be 2, 3 or 4 (the f16 pair)");
   M3D_CHECK_ARG(d_text && d_out, "m3d_head_pack_text_terms: null pointer");
   M3D_CHECK_ARG(n_classes >= 1 && n_classes <= classes_padded && classes_padded % 32 == 0 && cmid >= 32 && cmid % 32 == 0,
                 "m3d_head_pack_text_terms: bad sizes");
   const int64_t total = (int64_t)classes_padded * cmid;
+  if (terms == kFmtF16) {
+    hipLaunchKernelGGL(head_pack_text_f16_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, stream, d_text,
+                       n_classes, cmid, classes_padded, static_cast<_Float16*>(d_out));
+    M3D_LAUNCH_CHECK();
+    return M3D_OK;
+  }
   hipLaunchKernelGGL(head_pack_text3_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, stream, d_text, n_classes,
                      cmid, classes_padded, static_cast<__bf16*>(d_out));
   M3D_LAUNCH_CHECK();
   return M3D_OK;
 }
 
-extern "C" int m3d_head_fused_sf32(const void* d_in_split, int cin, int64_t n, const void* d_w1, const float* d_scale,
-                                   const float* d_shift, int cmid, const void* d_text_packed, int classes_padded,
-                                   int n_classes, float* d_logits, int64_t ldl, int32_t* d_voxel_label,
-                                   void* stream_) {
+static int head_fused_two_terms(bool f16, const void* d_in_split, int cin, int64_t n, const void* d_w1,
+                                const float* d_scale, const float* d_shift, int cmid, const void* d_text_packed,
+                                int classes_padded, int n_classes, float* d_logits, int64_t ldl,
+                                int32_t* d_voxel_label, void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   if (n == 0) return M3D_OK;
   M3D_CHECK_ARG(d_in_split && d_w1 && d_text_packed, "m3d_head_fused_sf32: null pointer");
@@ -644,7 +703,7 @@ extern "C" int m3d_head_fused_sf32(const void* d_in_split, int cin, int64_t n, c
   M3D_CHECK_ARG(n > 0 && cmid >= 32 && cmid % 32 == 0 && n_classes >= 1 && n_classes <= classes_padded,
                 "m3d_head_fused_sf32: bad sizes");
   M3D_CHECK_ARG(d_logits == nullptr || ldl >= n_classes, "m3d_head_fused_sf32: logits rows shorter than n_classes");
-  HeadArgs a;
+  HeadArgs a = {};
   a.x = static_cast<const char*>(d_in_split);
   a.w1 = static_cast<const char*>(d_w1);
   a.w2 = static_cast<const char*>(d_text_packed);
@@ -656,13 +715,17 @@ extern "C" int m3d_head_fused_sf32(const void* d_in_split, int cin, int64_t n, c
   a.n = n;
   a.cmid = cmid;
   a.n_classes = n_classes;
+  if (f16) {
+    if (int rc = f16_status_ptr(&a.f16_status)) return rc;
+  }
   if (cmid > kHeadMaxFeatures) {
     set_error("m3d_head_fused_sf32: at most %d feature channels (got %d)", kHeadMaxFeatures, cmid);
     return M3D_EINVAL;
   }
   // 8 waves x 32 rows per workgroup where the DMA slot count divides by 512 threads, else 4 waves
-#define M3D_HEAD_CASE(CIN_, CP_, NW_) \
-  if (cin == CIN_ && classes_padded == CP_) return launch_head<CIN_ / 32, CP_ / 32, NW_>(a, stream);
+#define M3D_HEAD_CASE(CIN_, CP_, NW_)                                                                 \
+  if (cin == CIN_ && classes_padded == CP_)                                                            \
+    return f16 ? launch_head<CIN_ / 32, CP_ / 32, NW_, true>(a, stream) : launch_head<CIN_ / 32, CP_ / 32, NW_, false>(a, stream);
   M3D_HEAD_CASE(96, 32, 8) M3D_HEAD_CASE(96, 96, 8) M3D_HEAD_CASE(96, 160, 8) M3D_HEAD_CASE(96, 224, 8)
   M3D_HEAD_CASE(96, 64, 4) M3D_HEAD_CASE(96, 128, 4) M3D_HEAD_CASE(96, 192, 4) M3D_HEAD_CASE(96, 256, 4)
   M3D_HEAD_CASE(32, 128, 4) M3D_HEAD_CASE(32, 256, 4) M3D_HEAD_CASE(64, 128, 8) M3D_HEAD_CASE(64, 256, 8)
@@ -673,16 +736,24 @@ extern "C" int m3d_head_fused_sf32(const void* d_in_split, int cin, int64_t n, c
   return M3D_EINVAL;
 }
 
+extern "C" int m3d_head_fused_sf32(const void* d_in_split, int cin, int64_t n, const void* d_w1, const float* d_scale,
+                                   const float* d_shift, int cmid, const void* d_text_packed, int classes_padded,
+                                   int n_classes, float* d_logits, int64_t ldl, int32_t* d_voxel_label,
+                                   void* stream_) {
+  return head_fused_two_terms(false, d_in_split, cin, n, d_w1, d_scale, d_shift, cmid, d_text_packed, classes_padded,
+                              n_classes, d_logits, ldl, d_voxel_label, stream_);
+}
+
 extern "C" int m3d_head_fused_terms(const void* d_in_split, int cin, int64_t n, int terms, const void* d_w1,
                                     const float* d_scale, const float* d_shift, int cmid, const void* d_text_packed,
                                     int classes_padded, int n_classes, float* d_logits, int64_t ldl,
                                     int32_t* d_voxel_label, void* stream_) {
-  if (terms == 2)
-    return m3d_head_fused_sf32(d_in_split, cin, n, d_w1, d_scale, d_shift, cmid, d_text_packed, classes_padded, n_classes,
-                               d_logits, ldl, d_voxel_label, stream_);
+  if (terms == 2 || terms == kFmtF16)
+    return head_fused_two_terms(terms == kFmtF16, d_in_split, cin, n, d_w1, d_scale, d_shift, cmid, d_text_packed,
+                                classes_padded, n_classes, d_logits, ldl, d_voxel_label, stream_);
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   const char* who = "m3d_head_fused_terms";
-  M3D_CHECK_ARG(terms == 3, "%s: terms must be 2 or 3", who);
+  M3D_CHECK_ARG(terms == 3, "%s: terms must be 2, 3 or 4 (the f16 pair)", who);
   if (n == 0) return M3D_OK;
   M3D_CHECK_ARG(d_in_split && d_w1 && d_text_packed, "%s: null pointer", who);
   M3D_CHECK_ARG(d_logits || d_voxel_label, "%s: no output requested", who);

@@ -69,6 +69,9 @@ class SpUNetEngine:
     def _init(self, model_or_state, cfg, condition, precision):
         sd = model_or_state.state_dict() if hasattr(model_or_state, "state_dict") else dict(model_or_state)
         sd = {k: v.detach().to("cpu") for k, v in sd.items()}
+        self._state = sd        # kept for the wider-range twin that predict_checked falls back to
+        self._twin = None
+        self._emb = None
         self.cfg = cfg
         self.precision = precision
         # schedule mode of the submanifold maps per level (the last entry repeats): rows regrouped by neighbour
@@ -100,7 +103,7 @@ class SpUNetEngine:
             else:
                 a = None
                 c = bsd[bias].float().contiguous() if bias is not None and bias in bsd else None
-            return _Conv(w, None if a is None else a.to(self.device), None if c is None else c.to(self.device))
+            return self._make_conv(w, a, c)
 
         def block(prefix):
             d = dict(conv1=conv(f"{prefix}.conv1.weight", f"{prefix}.bn1"),
@@ -121,6 +124,24 @@ class SpUNetEngine:
         self.n_classes = 0
         self.last_stats = {}
 
+    def _make_conv(self, w, scale, shift):
+        """A layer record; a weight packed with a power-of-two factor ("f16x3") has the inverse folded into the
+        epilogue's scale vector here, once, so that the per-call path never forms it."""
+        if scale is not None:
+            scale = scale.to(self.device)
+        if w.exp:
+            scale = (torch.ones(w.cout, device=self.device) if scale is None else scale) * w.unscale
+            w.exp = 0
+        return _Conv(w, None if scale is None else scale.float().contiguous(),
+                     None if shift is None else shift.to(self.device))
+
+    def f16_range_exceeded(self, clear=True):
+        """Precision "f16x3" only: True if an activation left the f16 range (|x| > 65504) in any call on this device
+        since the status was last cleared; such results are invalid and should be redone with "bf16x6".  Waits for
+        the GPU."""
+        with torch.cuda.device(self.device):
+            return ops.f16_status(clear)
+
     # ------------------------------------------------------------------ head
     def set_text_embeddings(self, emb: torch.Tensor):
         """emb [C, D] (rows are unit-norm CLIP text features, clip_alignment_loss.py:123-124)."""
@@ -129,17 +150,20 @@ class SpUNetEngine:
 
     def _set_text_embeddings(self, emb: torch.Tensor):
         emb = emb.detach().float().to(self.device)
+        self._emb = emb
+        if self._twin is not None:
+            self._twin.set_text_embeddings(emb)
         c, d = emb.shape
         if d != self.final.cout:
             raise ValueError(f"text dim {d} does not match the backbone output {self.final.cout}")
         cpad = 32 if c <= 32 else 64 if c <= 64 else 96 if c <= 96 else (c + 127) // 128 * 128
         w = torch.zeros((cpad, 1, d), dtype=torch.float32, device=self.device)
         w[:c, 0] = emb
-        self.text = _Conv(ops.pack_weight(w, self.head_precision), None, None)
+        self.text = self._make_conv(ops.pack_weight(w, self.head_precision), None, None)
         self.n_classes = c
         # one-kernel head (last 1x1 layer + logits + argmax): 2- and 3-term split precisions, supported shapes only
         self.text_fused = None
-        if self._terms in (2, 3) and self.fuse_head and ops.head_fused_supported(self.final.w.cin, c):
+        if self._terms in (2, 3, 4) and self.fuse_head and ops.head_fused_supported(self.final.w.cin, c):
             self.text_fused = ops.head_pack_text(emb, cin=self.final.w.cin, terms=self._terms)
         # folded head: logits = x96 . (E Wf)^T + E bf   (no nonlinearity between `final` and the head)
         wf = self._sd["final.weight"].reshape(self.final.cout, -1).double().to(self.device)
@@ -148,7 +172,7 @@ class SpUNetEngine:
         bfold = torch.zeros((cpad,), dtype=torch.float32, device=self.device)
         if "final.bias" in self._sd:
             bfold[:c] = (emb.double() @ self._sd["final.bias"].double().to(self.device)).float()
-        self.text_folded = _Conv(ops.pack_weight(wfold, self.precision), None, bfold.contiguous())
+        self.text_folded = self._make_conv(ops.pack_weight(wfold, self.precision), None, bfold.contiguous())
 
     # ------------------------------------------------------------------ kernel maps
     def _subm_schedule(self, l, pair, n, indices, shape, batch_size):
@@ -295,6 +319,23 @@ class SpUNetEngine:
             raise ValueError("fold_head never forms the features; it cannot return them")
         with torch.cuda.device(self.device):
             return self._predict(coord, feat, offset, grid_size, fold_head, return_logits, return_features)
+
+    def predict_checked(self, coord, feat, offset, grid_size, **kw):
+        """predict() with the range check of precision "f16x3" applied: the call waits for its result, reads the
+        device's f16 status and, if an activation left the f16 range, computes the scene again with an engine of
+        precision "bf16x6" built from the same parameters (kept for later calls).  Other precisions: plain predict().
+        The returned dict carries "precision", the precision that produced it."""
+        if self.precision != "f16x3":
+            return dict(self.predict(coord, feat, offset, grid_size, **kw), precision=self.precision)
+        self.f16_range_exceeded(clear=True)  # leftovers of earlier, unchecked calls are not this call's business
+        out = self.predict(coord, feat, offset, grid_size, **kw)
+        if not self.f16_range_exceeded(clear=True):
+            return dict(out, precision="f16x3")
+        if self._twin is None:
+            self._twin = SpUNetEngine(self._state, self.cfg, self.condition, self.device, precision="bf16x6")
+            if self._emb is not None:
+                self._twin.set_text_embeddings(self._emb)
+        return dict(self._twin.predict(coord, feat, offset, grid_size, **kw), precision="bf16x6")
 
     def _predict(self, coord, feat, offset, grid_size, fold_head, return_logits, return_features=False):
         vlabel = None

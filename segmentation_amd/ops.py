@@ -6,6 +6,7 @@ import ctypes
 from dataclasses import dataclass
 from typing import Optional, Sequence
 
+import numpy as np
 import torch
 
 from . import _lib
@@ -273,9 +274,23 @@ def build_schedule(pair, n, indices=None, mode=0, spatial_shape=None, batch_size
 
 
 # ----------------------------------------------------------------------------- convolution
-PRECISION = {"f32": 0, "bf16x3": 1, "bf16x6": 2, "bf16": 3}
-TERMS = {"f32": 0, "bf16": 1, "bf16x3": 2, "bf16x6": 3}          # terms of the split format each precision consumes
-PRECISION_OF_TERMS = {1: "bf16", 2: "bf16x3", 3: "bf16x6"}
+PRECISION = {"f32": 0, "bf16x3": 1, "bf16x6": 2, "bf16": 3, "f16x3": 4}
+# split-format code each precision consumes: the number of bf16 terms, or 4 = the f16 pair (M3D_FMT_F16_PAIR)
+TERMS = {"f32": 0, "bf16": 1, "bf16x3": 2, "bf16x6": 3, "f16x3": 4}
+PRECISION_OF_TERMS = {1: "bf16", 2: "bf16x3", 3: "bf16x6", 4: "f16x3"}
+FMT_F16_PAIR = 4
+
+
+def f16_status(clear=True):
+    """True if a kernel on the current device wrote a value beyond the f16 range into the f16 pair format since the
+    status was last cleared (m3d_f16_status; waits for the current stream).  Results of precision "f16x3" computed
+    while it was set are not to be trusted."""
+    import ctypes
+    lib = _lib.load()
+    v = ctypes.c_int(0)
+    rc = lib.m3d_f16_status(ctypes.byref(v), int(bool(clear)), _stream())
+    _lib.check(rc, "m3d_f16_status")
+    return bool(v.value)
 
 
 @dataclass
@@ -286,6 +301,24 @@ class PackedWeight:
     cout: int
     cin: int
     precision: str
+    # "f16x3": the weight was multiplied by 2**exp before packing (largest magnitude near 2**14, the whole tensor
+    # inside the f16 normal range); conv_fwd and head_fused multiply the result by unscale = 2**-exp again
+    exp: int = 0
+    unscale_vec: object = None  # [cout] f32 filled with 2**-exp (made on first use by a call without a scale vector)
+
+    @property
+    def unscale(self):
+        return 2.0 ** -self.exp
+
+    def scale_with_unscale(self, scale):
+        """The per-channel scale of the epilogue with the weight's power of two folded in."""
+        if self.exp == 0:
+            return scale
+        if scale is None:
+            if self.unscale_vec is None:
+                self.unscale_vec = torch.full((self.cout,), self.unscale, dtype=torch.float32, device=self.data.device)
+            return self.unscale_vec
+        return scale * self.unscale
 
 
 def pack_weight(weight, precision="f32", device=None, transposed=False, flip=False):
@@ -301,17 +334,25 @@ def pack_weight(weight, precision="f32", device=None, transposed=False, flip=Fal
         w = w.to(device)
     _need_cuda(w)
     prec = PRECISION[precision]
+    exp = 0
+    if precision == "f16x3" and cin % 32 == 0 and cout % 32 == 0:
+        # an exact power-of-two rescale into the upper part of the f16 range (reads the maximum back: packing a
+        # weight for this precision synchronises, which is why it is for inference engines, packed once)
+        wmax = float(w.abs().max())
+        if wmax > 0 and np.isfinite(wmax):
+            exp = int(np.clip(14 - int(np.ceil(np.log2(wmax))), -60, 60))
+            w = w * (2.0 ** exp)
     if transposed:
         nbytes = lib.m3d_conv_packed_weight_bytes(cin, k, cout, prec)
         out = torch.empty((nbytes,), dtype=torch.uint8, device=w.device)
         rc = lib.m3d_conv_pack_weight_transposed(_ptr(w), cout, k, cin, int(bool(flip)), prec, _ptr(out), _stream())
         _lib.check(rc, "m3d_conv_pack_weight_transposed")
-        return PackedWeight(out, k, cin, cout, precision)
+        return PackedWeight(out, k, cin, cout, precision, exp)
     nbytes = lib.m3d_conv_packed_weight_bytes(cout, k, cin, prec)
     out = torch.empty((nbytes,), dtype=torch.uint8, device=w.device)
     rc = lib.m3d_conv_pack_weight(_ptr(w), cout, k, cin, prec, _ptr(out), _stream())
     _lib.check(rc, "m3d_conv_pack_weight")
-    return PackedWeight(out, k, cout, cin, precision)
+    return PackedWeight(out, k, cout, cin, precision, exp)
 
 
 @dataclass
@@ -341,6 +382,10 @@ def split_f32(x, terms):
 
 def unsplit(st: SplitTensor):
     """sf32 -> f32 (sum of the terms); for tests and debugging."""
+    if st.terms == FMT_F16_PAIR:
+        t = st.data.view(torch.float16).view(st.n + 1, st.c // 32, 2, 32).float()
+        v = t[:, :, 0] + t[:, :, 1] * (1.0 / 2048.0)
+        return v.reshape(st.n + 1, st.c)[:st.n].contiguous()
     g = 16 if st.terms == 3 else 32
     v = st.data.view(torch.bfloat16).view(st.n + 1, st.c // g, st.terms, g).float().sum(2)
     return v.reshape(st.n + 1, st.c)[:st.n]
@@ -373,12 +418,13 @@ def conv_fwd(in0, weight_packed: PackedWeight, sched: Optional[Schedule], n_out,
         assert in0.is_contiguous() and in0.dtype == torch.float32
         assert in1 is None or (in1.is_contiguous() and in1.dtype == torch.float32)
         dev = in0.device
-    if split_terms not in (0, 1, 2, 3):
-        raise ValueError("split_terms must be 0, 1, 2 or 3")
+    if split_terms not in (0, 1, 2, 3, 4):
+        raise ValueError("split_terms must be 0, 1, 2, 3 or 4 (the f16 pair)")
     if sf_in and split_terms and split_terms != in0.terms:
         raise ValueError("the split output of an sf32 convolution uses the input's number of terms")
     if not want_f32 and split_terms == 0:
         raise ValueError("nothing to compute: want_f32=False and split_terms=0")
+    scale = weight_packed.scale_with_unscale(scale)
     if out is None and want_f32:
         out = torch.empty((n_out, cout), dtype=torch.float32, device=dev)
     if out is not None:
@@ -576,8 +622,8 @@ def head_pack_text(text, cin=96, classes_padded=None, terms=2):
     cp = classes_padded or ((c + 31) // 32 * 32 if cin == 96 else (128 if c <= 128 else 256))
     if c > cp or d % 32 != 0:
         raise ValueError(f"head_pack_text: {c} classes x {d} channels not supported")
-    if terms not in (2, 3):
-        raise ValueError("head_pack_text: the fused head exists for 2 and 3 terms")
+    if terms not in (2, 3, 4):
+        raise ValueError("head_pack_text: the fused head exists for 2 and 3 bf16 terms and the f16 pair (4)")
     out = torch.empty((lib.m3d_head_text_bytes_terms(cp, d, terms),), dtype=torch.uint8, device=text.device)
     rc = lib.m3d_head_pack_text_terms(_ptr(text), c, d, cp, terms, _ptr(out), _stream())
     _lib.check(rc, "m3d_head_pack_text_terms")
@@ -592,7 +638,8 @@ def head_fused(x: "SplitTensor", w1: "PackedWeight", text: PackedText, scale=Non
                want_labels=True):
     """Last 1x1 layer + text logits + row argmax in one kernel.  Returns (voxel_label or None, logits or None)."""
     lib = _lib.load()
-    assert x.terms in (2, 3) and x.terms == text.terms and w1.precision == PRECISION_OF_TERMS[x.terms]
+    assert x.terms in (2, 3, 4) and x.terms == text.terms and w1.precision == PRECISION_OF_TERMS[x.terms]
+    scale = w1.scale_with_unscale(scale)
     assert w1.k == 1 and w1.cout == text.cmid and w1.cin == x.c
     n, dev = x.n, x.data.device
     label = torch.empty((n,), dtype=torch.int32, device=dev) if want_labels else None

@@ -1,6 +1,6 @@
 """The LDS-DMA convolution on split-format (sf32) activations (m3d_conv_fwd_sf32, m3d_split_f32) against the
 CPU oracle.  Tolerances, per-row relative L2 over one layer: terms=3 (bf16x6) 1e-5, terms=2 (bf16x3) 6e-5,
-terms=1 (plain bf16 operands, f32 accumulation) 1e-2."""
+terms=1 (plain bf16 operands, f32 accumulation) 1e-2, format 4 (f16x3: operands as f16 pairs exact to 2^-22) 1e-5."""
 import numpy as np
 import pytest
 import torch
@@ -9,13 +9,14 @@ import oracle
 from segmentation_amd import ops, scenes
 
 pytestmark = pytest.mark.gpu
-TOL = {3: 1e-5, 2: 6e-5, 1: 1e-2}
-PREC = {3: "bf16x6", 2: "bf16x3", 1: "bf16"}
-SPLIT_TOL = {3: 2.0 ** -23, 2: 2.0 ** -16, 1: 2.0 ** -8}
+TOL = {3: 1e-5, 2: 6e-5, 1: 1e-2, 4: 1e-5}
+PREC = {3: "bf16x6", 2: "bf16x3", 1: "bf16", 4: "f16x3"}
+SPLIT_TOL = {3: 2.0 ** -23, 2: 2.0 ** -16, 1: 2.0 ** -8, 4: 2.0 ** -21}
+FORMATS = [1, 2, 3, 4]
 
 
 def _zero_row_is_zero(st):
-    row_bytes = st.c * st.terms * 2
+    row_bytes = st.c * (2 if st.terms == 4 else st.terms) * 2
     return bool((st.data[st.n * row_bytes:(st.n + 1) * row_bytes] == 0).all()) and st.data.numel() == (st.n + 1) * row_bytes
 
 
@@ -38,19 +39,20 @@ def level(device):
                 sched_up=ops.build_schedule(pb, idx.shape[0], None, 2, base_order=sched.out_row))
 
 
-@pytest.mark.parametrize("terms", [1, 2, 3])
+@pytest.mark.parametrize("terms", FORMATS)
 def test_split_roundtrip(device, terms):
     g = torch.Generator().manual_seed(0)
-    x = torch.randn(1000, 96, generator=g) * torch.logspace(-6, 6, 96)
+    # the f16 pair covers the f16 range only, and resolves 2^-36 at best
+    x = torch.randn(1000, 96, generator=g) * (torch.logspace(-6, 6, 96) if terms != 4 else torch.logspace(-5, 3.5, 96))
     st = ops.split_f32(x.to(device), terms)
     back = ops.unsplit(st).cpu()
-    assert ((back - x).abs() <= SPLIT_TOL[terms] * x.abs()).all()
+    assert ((back - x).abs() <= SPLIT_TOL[terms] * x.abs() + (2.0 ** -35 if terms == 4 else 0.0)).all()
     assert _zero_row_is_zero(st)
     if terms == 1:  # one term is plain row-major bf16
         assert torch.equal(st.data.view(torch.bfloat16).view(1001, 96)[:1000].cpu(), x.to(torch.bfloat16))
 
 
-@pytest.mark.parametrize("terms", [1, 2, 3])
+@pytest.mark.parametrize("terms", FORMATS)
 @pytest.mark.parametrize("cin,cout", [(32, 32), (64, 64), (96, 96), (128, 96), (128, 128), (256, 256), (384, 256)])
 def test_subm_conv(device, level, cin, cout, terms):
     g = torch.Generator().manual_seed(cin * 1000 + cout)
@@ -62,7 +64,7 @@ def test_subm_conv(device, level, cin, cout, terms):
     assert _rel(out, ref) < TOL[terms]
 
 
-@pytest.mark.parametrize("terms", [1, 2, 3])
+@pytest.mark.parametrize("terms", FORMATS)
 def test_fused_epilogue_two_sources_and_split_output(device, level, terms):
     g = torch.Generator().manual_seed(7)
     n = level["idx"].shape[0]
@@ -77,7 +79,7 @@ def test_fused_epilogue_two_sources_and_split_output(device, level, terms):
     assert _rel(out, ref) < TOL[terms]
     # the split copy is the same tensor in sf32, zero row included
     back = ops.unsplit(osp)
-    assert ((back - out).abs() <= SPLIT_TOL[terms] * out.abs()).all()
+    assert ((back - out).abs() <= SPLIT_TOL[terms] * out.abs() + (2.0 ** -35 if terms == 4 else 0.0)).all()
     assert _zero_row_is_zero(osp)
     # split-only output
     none, osp2 = ops.conv_fwd(ops.split_f32(xa.to(device), terms), ops.pack_weight(w, PREC[terms], device),
@@ -87,7 +89,7 @@ def test_fused_epilogue_two_sources_and_split_output(device, level, terms):
     assert none is None and torch.equal(osp2.data, osp.data)
 
 
-@pytest.mark.parametrize("terms", [1, 2, 3])
+@pytest.mark.parametrize("terms", FORMATS)
 @pytest.mark.parametrize("cin,cout", [(32, 64), (128, 256)])
 def test_strided_and_inverse(device, level, cin, cout, terms):
     g = torch.Generator().manual_seed(cin + cout)
@@ -104,7 +106,7 @@ def test_strided_and_inverse(device, level, cin, cout, terms):
     assert _rel(out_i, ref_i) < TOL[terms]
 
 
-@pytest.mark.parametrize("terms", [1, 2, 3])
+@pytest.mark.parametrize("terms", FORMATS)
 @pytest.mark.parametrize("n,cin,cout", [(5000, 96, 768), (700, 384, 256), (130, 128, 96), (1, 96, 32), (70000, 128, 96)])
 def test_dense_1x1(device, n, cin, cout, terms):
     g = torch.Generator().manual_seed(n)
@@ -116,7 +118,7 @@ def test_dense_1x1(device, n, cin, cout, terms):
     assert _rel(out, ref) < TOL[terms]
 
 
-@pytest.mark.parametrize("terms", [1, 2, 3])
+@pytest.mark.parametrize("terms", FORMATS)
 @pytest.mark.parametrize("target", [300, 1500, 30000])
 def test_all_tile_configurations(device, target, terms):
     sc = scenes.make_scene(seed=9, target_voxels=target)
@@ -135,7 +137,7 @@ def test_all_tile_configurations(device, target, terms):
         assert _rel(out, ref) < TOL[terms], (target, cin, cout)
 
 
-@pytest.mark.parametrize("terms", [2, 3])
+@pytest.mark.parametrize("terms", [2, 3, 4])
 @pytest.mark.parametrize("target", [300, 1500, 12000])
 def test_f32_rows_with_split_products_equal_the_presplit_path(device, target, terms):
     """m3d_conv_fwd_f32 at precision bf16x3 / bf16x6 gathers plain f32 rows into LDS and forms the terms after the
@@ -181,3 +183,20 @@ def test_f32_rows_with_split_products_equal_the_presplit_path(device, target, te
     x96 = torch.randn(n, 96, generator=g).to(device)
     assert torch.equal(ops.conv_fwd(x96, w1, None, n), ops.conv_fwd(ops.split_f32(x96, terms), w1, None, n))
 
+
+
+def test_f16_status_reports_values_beyond_the_f16_range(device):
+    """The f16 pair cannot hold |x| > 65504: a kernel that meets such a value sets the status word."""
+    ops.f16_status(clear=True)
+    x = torch.randn(500, 64, device=device)
+    ops.split_f32(x, 4)
+    assert ops.f16_status(clear=True) is False
+    x[17, 5] = 7.0e4
+    ops.split_f32(x, 4)
+    assert ops.f16_status(clear=True) is True
+    assert ops.f16_status(clear=True) is False
+    # a convolution whose output leaves the range reports it through its split output
+    w = ops.pack_weight(torch.full((32, 1, 1, 1, 64), 100.0), "f16x3", device)
+    big = torch.full((300, 64), 50.0, device=device)
+    ops.conv_fwd(ops.split_f32(big, 4), w, None, 300, split_terms=4)
+    assert ops.f16_status(clear=True) is True

@@ -17,12 +17,12 @@ from segmentation_amd.engine import SpUNetEngine
 
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
-TOL = {"f32": 1e-4, "bf16x6": 1e-4, "bf16x3": 1e-4, "bf16": 5e-2}
+TOL = {"f32": 1e-4, "bf16x6": 1e-4, "f16x3": 1e-4, "bf16x3": 1e-4, "bf16": 5e-2}
 # the generator's constants (tests/golden/make_golden_forward.py)
 SEEDS, TARGET, PARAM_SEED, CONDITION = [21, 22], 5000, 3, "Structured3D"
 
 
-@pytest.mark.parametrize("prec", ["f32", "bf16x6", "bf16x3", "bf16"])
+@pytest.mark.parametrize("prec", ["f32", "bf16x6", "f16x3", "bf16x3", "bf16"])
 def test_engine_matches_the_reference_forward_golden(device, prec):
     g = np.load(os.path.join(HERE, "golden", "reference_forward_v1m3.npz"))
     cfg = ospunet.SPUNET34C
@@ -31,8 +31,14 @@ def test_engine_matches_the_reference_forward_golden(device, prec):
     sd = {("backbone." + k if not k.startswith("embedding_table") else k): v for k, v in P.items()}
     eng = SpUNetEngine(sd, cfg, CONDITION, device, precision=prec)
     keep = {}
+    eng.f16_range_exceeded(clear=True)
     feats, vox = eng.forward_features(torch.from_numpy(b["coord"]).to(device), torch.from_numpy(b["feat"]).to(device),
                                       b["offset"], 0.02, keep=keep)
+    if prec == "f16x3":
+        # the golden network's activations grow far beyond the f16 range with depth: what this precision owes here
+        # is to say so (tests/test_gpu_spunet.py checks its accuracy on a network that stays in range)
+        assert eng.f16_range_exceeded(clear=True) is True
+        return
     assert np.array_equal(vox["voxel_coords"].cpu().numpy(), g["voxel_coords"])
     assert np.array_equal(vox["v2p_map"].cpu().numpy(), g["v2p_map"])
     assert list(vox["spatial_shape"]) == list(g["sparse_shape"])

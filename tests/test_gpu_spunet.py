@@ -59,6 +59,53 @@ def test_engine_matches_oracle(device, case, prec):
         eng.predict(coord, feat, b["offset"], 0.02, fold_head=True, return_features=True)
 
 
+def test_f16_pairs_outside_their_range_are_detected_and_redone(device, case):
+    """The activations of this synthetic network grow to 1e9 with depth, far beyond the f16 range: precision "f16x3"
+    must notice (the device's status word) and predict_checked must deliver the result of the bf16x6 twin."""
+    cfg, P, b = case["cfg"], case["P"], case["b"]
+    assert max(float(v.abs().max()) for v in case["inter"].values()) > 1e6
+    sd = {("backbone." + k if not k.startswith("embedding_table") else k): v for k, v in P.items()}
+    eng = SpUNetEngine(sd, cfg, "Matterport3D", device, precision="f16x3")
+    eng.set_text_embeddings(case["emb"])
+    coord, feat = torch.from_numpy(b["coord"]).to(device), torch.from_numpy(b["feat"]).to(device)
+    eng.f16_range_exceeded(clear=True)
+    eng.predict(coord, feat, b["offset"], 0.02)
+    assert eng.f16_range_exceeded(clear=True) is True
+    ref_pred = oracle.head_predict(case["ref"], case["sp"]["v2p_map"], case["emb"])
+    out = eng.predict_checked(coord, feat, b["offset"], 0.02, return_features=True)
+    assert out["precision"] == "bf16x6"
+    assert _rel_rows(out["voxel_feat"], case["ref"]) < 1e-4
+    assert (out["pred"].cpu() == ref_pred).float().mean().item() >= 0.999
+
+
+def test_f16_pairs_match_the_oracle_at_f32_level(device):
+    """Precision "f16x3" on a network whose activations stay in the f16 range (freshly initialised weights, unit
+    running statistics): every layer output and the final features within 1e-5 of the f32 CPU oracle (the bar of
+    the task is 1e-4), labels >= 99.9 %, and the range check stays clear."""
+    cfg = dict(ospunet.SPUNET34C, layers=(1, 1, 1, 1, 1, 1, 1, 1))
+    P = ospunet.make_spunet_params(cfg, seed=3, trained_like=False)
+    b = scenes.make_batch([21, 22], target_voxels=8000)
+    sp = oracle.sparsify(b["coord"], b["feat"], b["offset"], 0.02)
+    ref, inter = ospunet.spunet_forward(P, cfg, torch.from_numpy(sp["voxel_feats"]), sp["voxel_coords"],
+                                        sp["spatial_shape"], "ScanNet", return_intermediates=True)
+    assert max(float(v.abs().max()) for v in inter.values()) < 6e4
+    emb = torch.from_numpy(scenes.text_embeddings(200, cfg["out_channels"]))
+    sd = {("backbone." + k if not k.startswith("embedding_table") else k): v for k, v in P.items()}
+    eng = SpUNetEngine(sd, cfg, "ScanNet", device, precision="f16x3")
+    eng.set_text_embeddings(emb)
+    coord, feat = torch.from_numpy(b["coord"]).to(device), torch.from_numpy(b["feat"]).to(device)
+    keep = {}
+    eng.f16_range_exceeded(clear=True)
+    feats, vox = eng.forward_features(coord, feat, b["offset"], 0.02, keep=keep)
+    for name, r in inter.items():
+        assert _rel_rows(keep[name], r) < 1e-5, name
+    assert _rel_rows(feats, ref) < 1e-5
+    out = eng.predict_checked(coord, feat, b["offset"], 0.02)
+    assert out["precision"] == "f16x3"
+    ref_pred = oracle.head_predict(ref, sp["v2p_map"], emb)
+    assert (out["pred"].cpu() == ref_pred).float().mean().item() >= 0.999
+
+
 def test_module_path_matches_oracle(device, case):
     cfg, P, b = case["cfg"], case["P"], case["b"]
     model = spunet.PPT(spunet.SpUNet(**{k: cfg[k] for k in ("in_channels", "out_channels", "base_channels",
