@@ -8,8 +8,8 @@
  *
  * Conventions
  *   - every pointer named d_* is DEVICE memory owned by the caller (PyTorch tensors in practice);
- *     the library never allocates or frees device memory and keeps no global mutable state except
- *     a thread-local error string;
+ *     the library never allocates or frees device memory; its only state is a thread-local error string,
+ *     the per-device scratch of m3d_bn_stats_static and the per-device f16 status word (m3d_f16_status);
  *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it, nothing synchronises;
  *   - data-dependent output sizes (number of voxels) are written to device memory; outputs are
  *     sized by the caller for the worst case (one row per input row);
