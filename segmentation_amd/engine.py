@@ -17,6 +17,7 @@ spconv_unet_v1m3_pdnorm.py:380-414 in eval mode.  What is restructured for MI355
 """
 from typing import Dict, Optional, Sequence
 
+import collections
 import os
 import torch
 
@@ -337,30 +338,85 @@ class SpUNetEngine:
                 self._twin.set_text_embeddings(self._emb)
         return dict(self._twin.predict(coord, feat, offset, grid_size, **kw), precision="bf16x6")
 
-    def _predict(self, coord, feat, offset, grid_size, fold_head, return_logits, return_features=False):
+    def predict_many(self, scenes, fold_head=False, return_logits=False, return_features=False):
+        """predict() for a sequence of scenes, software-pipelined over two streams: while the network and the head
+        of scene i run on the current stream, the voxelizer and the map builders of scene i + 1 run on a side stream.
+        That first stage is a chain of ~170 small launches with two host read-backs and leaves most of the GPU idle;
+        beside the convolutions of the previous scene it costs little.  One host thread does both: it enqueues the
+        network of scene i (no read-back inside), then builds the maps of scene i + 1, whose read-backs wait for the
+        side stream only.  Results are those of predict(), scene by scene, in order.
+        scenes: iterable of (coord, feat, offset, grid_size); returns a list."""
+        if self.text is None:
+            raise RuntimeError("call set_text_embeddings() first")
+        if return_features and fold_head:
+            raise ValueError("fold_head never forms the features; it cannot return them")
+        with torch.cuda.device(self.device), torch.no_grad():
+            main = torch.cuda.current_stream()
+            side = self.__dict__.get("_side_stream")
+            if side is None:
+                side = self._side_stream = torch.cuda.Stream(device=self.device)
+            side.wait_stream(main)  # the inputs are ready where the caller's stream stands now
+
+            def first_stage(sc):
+                coord, feat, offset, grid_size = sc
+                with torch.cuda.stream(side):
+                    vox, levels = self._voxelize_and_maps(coord, feat, offset, grid_size)
+                    ready = torch.cuda.Event()
+                    ready.record(side)
+                return int(coord.shape[0]), vox, levels, ready
+
+            outs, alive = [], collections.deque()
+            it = iter(scenes)
+            nxt = next(it, None)
+            cur = first_stage(nxt) if nxt is not None else None
+            try:
+                while cur is not None:
+                    n_points, vox, levels, ready = cur
+                    main.wait_event(ready)
+                    outs.append(self._predict(None, None, None, None, fold_head, return_logits, return_features,
+                                              maps=(vox, levels, n_points)))
+                    # memory handed out on the side stream must outlive its use on this one: the scene's maps are
+                    # released only when the work enqueued up to here has finished
+                    done = torch.cuda.Event()
+                    done.record(main)
+                    alive.append((done, vox, levels))
+                    nxt = next(it, None)
+                    cur = first_stage(nxt) if nxt is not None else None
+                    while len(alive) > 2:
+                        alive.popleft()[0].synchronize()
+            finally:
+                side.synchronize()
+                for done, _, _ in alive:
+                    done.synchronize()
+            return outs
+
+    def _predict(self, coord, feat, offset, grid_size, fold_head, return_logits, return_features=False, maps=None):
         vlabel = None
         vfeat = None
+        if maps is None:
+            vox, levels = self._voxelize_and_maps(coord, feat, offset, grid_size)
+            n_points = int(coord.shape[0])
+        else:
+            vox, levels, n_points = maps
+        self.last_stats = dict(n_points=n_points, n_voxels=[levels[l].n for l in range(len(levels))])
         if self.text_fused is not None and not fold_head and not return_features:
             # `final`, the logits and the argmax in one kernel: the CLIP features stay on chip
-            vox, levels = self._voxelize_and_maps(coord, feat, offset, grid_size)
             x = self.backbone(vox["voxel_feats"], levels)
             vlabel, logits = ops.head_fused(x[1], self.final.w, self.text_fused, scale=self.final.scale,
                                             shift=self.final.shift, want_logits=return_logits)
-            self.last_stats = dict(n_points=int(coord.shape[0]), n_voxels=[levels[l].n for l in range(len(levels))])
         elif fold_head:
-            vox, levels = self._voxelize_and_maps(coord, feat, offset, grid_size)
             x = self.backbone(vox["voxel_feats"], levels)
             t = self.text_folded
             src = x[1] if self._terms else x[0]
             logits = ops.conv_fwd(src, t.w, None, levels[0].n, shift=t.shift, flop_cout=self.n_classes)
-            self.last_stats = dict(n_points=int(coord.shape[0]), n_voxels=[levels[l].n for l in range(len(levels))])
         else:
             # the head consumes the split features directly; the f32 copy is only written when asked for
-            pair, vox = self._forward_features(coord, feat, offset, grid_size, want_split=self._terms != 0,
-                                               want_f32=return_features)
-            src = pair[1] if self._terms else pair
-            vfeat = pair[0] if self._terms else pair
-            logits = ops.conv_fwd(src, self.text.w, None, self.last_stats["n_voxels"][0], flop_cout=self.n_classes)
+            x = self.backbone(vox["voxel_feats"], levels)
+            pair = self._conv(self.final, x, None, levels[0].n, need_f32=return_features or self._terms == 0,
+                              need_sf=self._terms != 0)
+            src = pair[1] if self._terms else pair[0]
+            vfeat = pair[0]
+            logits = ops.conv_fwd(src, self.text.w, None, levels[0].n, flop_cout=self.n_classes)
         if vlabel is None:
             vlabel = ops.argmax_rows(logits, self.n_classes)
         plabel = ops.gather_labels(vlabel, vox["v2p_map"])

@@ -38,3 +38,36 @@ def test_mixed_size_scenes_through_one_engine(device):
         # a batch shares one grid minimum (structure.py:219-220), so voxel boundaries may shift between the two
         # runs; labels agree except where a point changed voxel
         assert (out == ref).float().mean().item() > 0.97
+
+
+@pytest.mark.parametrize("prec", ["bf16x6", "f16x3", "f32"])
+def test_pipelined_scenes_equal_one_at_a_time(device, prec):
+    """predict_many (maps of scene i + 1 on a side stream while the network of scene i runs) returns, scene by scene,
+    exactly what predict returns -- labels, voxel labels, v2p maps -- also when scenes of very different sizes
+    follow one another, with logits and features on request, and twice in a row."""
+    import bench
+    eng, _, _ = bench.build_engine(device, prec)
+    rng = np.random.default_rng(5)
+    seq = []
+    for i, target in enumerate([9000, 700, 30000, 2500, 30000, 150]):
+        sc = scenes.make_scene(seed=40 + i, target_voxels=target)
+        n = sc["coord"].shape[0]
+        seq.append((torch.from_numpy(sc["coord"]).to(device), torch.from_numpy(sc["feat"]).to(device),
+                    np.array([0, n], dtype=np.int64), 0.02))
+    with torch.no_grad():
+        ref = [eng.predict(*sc, return_logits=True) for sc in seq]
+        for _ in range(2):
+            got = eng.predict_many(seq, return_logits=True)
+            assert len(got) == len(ref)
+            for a, b in zip(got, ref):
+                assert a["n_voxels"] == b["n_voxels"]
+                assert torch.equal(a["pred"], b["pred"]) and torch.equal(a["voxel_pred"], b["voxel_pred"])
+                assert torch.equal(a["v2p_map"], b["v2p_map"]) and torch.equal(a["voxel_logits"], b["voxel_logits"])
+        feats = eng.predict_many(seq[:3], return_features=True)
+        for a, sc in zip(feats, seq[:3]):
+            b = eng.predict(*sc, return_features=True)
+            assert torch.equal(a["voxel_feat"], b["voxel_feat"]) and torch.equal(a["pred"], b["pred"])
+        assert eng.predict_many([]) == []
+    # an error in the first stage of a later scene reaches the caller
+    with pytest.raises(Exception):
+        eng.predict_many([seq[0], (seq[1][0].cpu(), seq[1][1], seq[1][2], 0.02)])
