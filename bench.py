@@ -150,6 +150,8 @@ def main():
                     help="how products are formed: exact f32 MFMA, bf16 MFMA on 3-/2-term splits of f32, plain bf16")
     ap.add_argument("--fold-head", action="store_true", help="fold `final` into the text matrix (not the headline)")
     ap.add_argument("--no-variants", action="store_true", help="skip the measurements of the other precisions")
+    ap.add_argument("--net-streams", type=int, default=2,
+                    help="streams the networks of consecutive scenes are dealt to (predict_many); 1 = one network at a time")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="finish every scene before the next one starts (predict) instead of overlapping the map "
                          "building of the next scene with the network of the current one (predict_many)")
@@ -238,10 +240,10 @@ def main():
         """K passes over this rank's scenes as ONE sequence through predict_many: consecutive scenes overlap (the
         voxelizer and map builders of the next scene run on a side stream beside the network of the current one);
         every scene is still computed in full, results identical to one-at-a-time calls."""
-        e.predict_many(seq(warmup), fold_head=fold)
+        e.predict_many(seq(warmup), fold_head=fold, net_streams=args.net_streams)
         barrier()
         t0 = time.perf_counter()
-        outs = e.predict_many(seq(steps), fold_head=fold)
+        outs = e.predict_many(seq(steps), fold_head=fold, net_streams=args.net_streams)
         barrier()
         return time.perf_counter() - t0, sum(o["n_voxels"] for o in outs)
 
@@ -280,7 +282,7 @@ def main():
                 if p == "f16x3":
                     e2.f16_range_exceeded(clear=True)
                 steps_v = max(args.steps, 3)
-                dt, nv = timed(lambda: step(e2, False), steps_v, 2) if args.no_pipeline else timed_many(e2, steps_v, 2)
+                dt, nv = timed(lambda: step(e2, False), steps_v, 2) if args.no_pipeline else timed_many(e2, steps_v, 4)
                 variants[p] = dict(ms_per_step=dt / steps_v * 1e3, voxels_per_s=nv / dt, dtype=DTYPE[p])
                 if p == "f16x3":  # the timed passes are valid only if no operand left the f16 range
                     variants[p]["f16_range_exceeded"] = bool(e2.f16_range_exceeded(clear=True))
@@ -355,7 +357,8 @@ def main():
                                 points_per_scene=st.get("n_points", 0), level_voxels=st.get("n_voxels"),
                                 parallelism=f"scene-sharded x{world}, no collectives" + (
                                     "" if args.no_pipeline else "; consecutive scenes of a rank software-pipelined over "
-                                    "two streams (voxelizer + maps of scene i+1 beside the network of scene i)"),
+                                    f"streams (voxelizer + maps of scene i+1 on a side stream, networks of consecutive scenes dealt to "
+                                    f"{args.net_streams} streams)"),
                                 fold_head=args.fold_head,
                                 precision=args.precision),
                     roofline=roofline, stages=stage_stats, cpu_baseline=cb, parity=parity, variants=variants or None)

@@ -338,13 +338,15 @@ class SpUNetEngine:
                 self._twin.set_text_embeddings(self._emb)
         return dict(self._twin.predict(coord, feat, offset, grid_size, **kw), precision="bf16x6")
 
-    def predict_many(self, scenes, fold_head=False, return_logits=False, return_features=False):
+    def predict_many(self, scenes, fold_head=False, return_logits=False, return_features=False, net_streams=1):
         """predict() for a sequence of scenes, software-pipelined over two streams: while the network and the head
         of scene i run on the current stream, the voxelizer and the map builders of scene i + 1 run on a side stream.
         That first stage is a chain of ~170 small launches with two host read-backs and leaves most of the GPU idle;
         beside the convolutions of the previous scene it costs little.  One host thread does both: it enqueues the
         network of scene i (no read-back inside), then builds the maps of scene i + 1, whose read-backs wait for the
         side stream only.  Results are those of predict(), scene by scene, in order.
+        net_streams=k deals the networks of consecutive scenes round-robin to the current stream and k - 1 more, so
+        that the latency-bound small levels of one scene run beside the large convolutions of another.
         scenes: iterable of (coord, feat, offset, grid_size); returns a list."""
         if self.text is None:
             raise RuntimeError("call set_text_embeddings() first")
@@ -356,6 +358,13 @@ class SpUNetEngine:
             if side is None:
                 side = self._side_stream = torch.cuda.Stream(device=self.device)
             side.wait_stream(main)  # the inputs are ready where the caller's stream stands now
+            nets = [main]
+            pool = self.__dict__.setdefault("_net_streams", [])
+            while len(pool) < net_streams - 1:
+                pool.append(torch.cuda.Stream(device=self.device))
+            for extra in pool[:max(0, net_streams - 1)]:
+                extra.wait_stream(main)
+                nets.append(extra)
 
             def first_stage(sc):
                 coord, feat, offset, grid_size = sc
@@ -372,22 +381,31 @@ class SpUNetEngine:
             try:
                 while cur is not None:
                     n_points, vox, levels, ready = cur
-                    main.wait_event(ready)
-                    outs.append(self._predict(None, None, None, None, fold_head, return_logits, return_features,
-                                              maps=(vox, levels, n_points)))
-                    # memory handed out on the side stream must outlive its use on this one: the scene's maps are
-                    # released only when the work enqueued up to here has finished
+                    net = nets[len(outs) % len(nets)]
+                    net.wait_event(ready)
+                    with torch.cuda.stream(net):
+                        out = self._predict(None, None, None, None, fold_head, return_logits, return_features,
+                                            maps=(vox, levels, n_points))
+                    if net is not main:  # the caller will use (and free) these on its own stream
+                        for v in out.values():
+                            if torch.is_tensor(v):
+                                v.record_stream(main)
+                    outs.append(out)
+                    # memory handed out on the side stream must outlive its use on the network's stream: the scene's
+                    # maps are released only when the work enqueued up to here has finished
                     done = torch.cuda.Event()
-                    done.record(main)
+                    done.record(net)
                     alive.append((done, vox, levels))
                     nxt = next(it, None)
                     cur = first_stage(nxt) if nxt is not None else None
-                    while len(alive) > 2:
+                    while len(alive) > 2 * len(nets):
                         alive.popleft()[0].synchronize()
             finally:
                 side.synchronize()
                 for done, _, _ in alive:
                     done.synchronize()
+                for net in nets[1:]:
+                    main.wait_stream(net)
             return outs
 
     def _predict(self, coord, feat, offset, grid_size, fold_head, return_logits, return_features=False, maps=None):

@@ -56,8 +56,8 @@ def test_pipelined_scenes_equal_one_at_a_time(device, prec):
                     np.array([0, n], dtype=np.int64), 0.02))
     with torch.no_grad():
         ref = [eng.predict(*sc, return_logits=True) for sc in seq]
-        for _ in range(2):
-            got = eng.predict_many(seq, return_logits=True)
+        for rep in range(3):
+            got = eng.predict_many(seq, return_logits=True, net_streams=1 + rep % 2)
             assert len(got) == len(ref)
             for a, b in zip(got, ref):
                 assert a["n_voxels"] == b["n_voxels"]

@@ -23,4 +23,14 @@ with torch.no_grad():
     torch.cuda.synchronize(); t2 = time.perf_counter()
     eng.predict_many([one] * K)
     torch.cuda.synchronize(); t3 = time.perf_counter()
-print(f"{prec}: one at a time {(t1 - t0) / K * 1e3:.3f} ms/scene, pipelined {(t3 - t2) / K * 1e3:.3f} ms/scene")
+    eng.predict_many([one] * 4, net_streams=2)
+    torch.cuda.synchronize(); t4 = time.perf_counter()
+    eng.predict_many([one] * K, net_streams=2)
+    torch.cuda.synchronize(); t5 = time.perf_counter()
+    eng.predict_many([one] * 6, net_streams=3)
+    torch.cuda.synchronize(); t6 = time.perf_counter()
+    eng.predict_many([one] * K, net_streams=3)
+    torch.cuda.synchronize(); t7 = time.perf_counter()
+print(f"{prec}: three network streams {(t7 - t6) / K * 1e3:.3f} ms/scene")
+print(f"{prec}: one at a time {(t1 - t0) / K * 1e3:.3f} ms/scene, pipelined {(t3 - t2) / K * 1e3:.3f} ms/scene, "
+      f"two network streams {(t5 - t4) / K * 1e3:.3f} ms/scene")
