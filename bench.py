@@ -315,7 +315,9 @@ def main():
         roofline = dict(bound="mfma", achieved=achieved, peak=peak, unit="TFLOP/s", frac=achieved / peak, traffic=traffic,
                         kernel=kname + " (all tile shapes)", launches_per_step=nl // psteps,
                         flop_per_launch=flops / nl, avg_launch_us=secs / nl * 1e6,
-                        conv_share_of_step=secs / psteps / (elapsed / args.steps),
+                        conv_ms_per_scene=secs / psteps / max(len(my), 1) * 1e3,
+                        measured="HIP events around every launch of scenes processed one at a time (a kernel that "
+                                 "has the GPU to itself); the timed region overlaps scenes, see config.parallelism",
                         peak_note="dense matrix peak of the instruction issued, in f32-product FLOP/s "
                                   "(bf16 MFMA peak / products per f32 product)")
         cb = parity = None
