@@ -44,6 +44,9 @@ def _fold_norm(sd: Dict[str, torch.Tensor], prefix: str, cond_idx: int, context:
     return a.float().contiguous(), c.float().contiguous()
 
 
+_PIPE_STREAMS = {}  # device index -> [side stream, extra network streams ...] of predict_many
+
+
 class _Conv:
     __slots__ = ("w", "scale", "shift", "cout")
 
@@ -332,13 +335,17 @@ class SpUNetEngine:
         out = self.predict(coord, feat, offset, grid_size, **kw)
         if not self.f16_range_exceeded(clear=True):
             return dict(out, precision="f16x3")
+        return dict(self._bf16x6_twin().predict(coord, feat, offset, grid_size, **kw), precision="bf16x6")
+
+    def _bf16x6_twin(self):
         if self._twin is None:
             self._twin = SpUNetEngine(self._state, self.cfg, self.condition, self.device, precision="bf16x6")
             if self._emb is not None:
                 self._twin.set_text_embeddings(self._emb)
-        return dict(self._twin.predict(coord, feat, offset, grid_size, **kw), precision="bf16x6")
+        return self._twin
 
-    def predict_many(self, scenes, fold_head=False, return_logits=False, return_features=False, net_streams=1):
+    def predict_many(self, scenes, fold_head=False, return_logits=False, return_features=False, net_streams=1,
+                     check_range=False):
         """predict() for a sequence of scenes, software-pipelined over two streams: while the network and the head
         of scene i run on the current stream, the voxelizer and the map builders of scene i + 1 run on a side stream.
         That first stage is a chain of ~170 small launches with two host read-backs and leaves most of the GPU idle;
@@ -347,22 +354,33 @@ class SpUNetEngine:
         side stream only.  Results are those of predict(), scene by scene, in order.
         net_streams=k deals the networks of consecutive scenes round-robin to the current stream and k - 1 more, so
         that the latency-bound small levels of one scene run beside the large convolutions of another.
+        check_range (precision "f16x3" only): read the f16 status word after the last scene and, if an activation
+        left the f16 range anywhere, compute the whole sequence again with the bf16x6 twin (as predict_checked does
+        for one scene).
         scenes: iterable of (coord, feat, offset, grid_size); returns a list."""
         if self.text is None:
             raise RuntimeError("call set_text_embeddings() first")
         if return_features and fold_head:
             raise ValueError("fold_head never forms the features; it cannot return them")
+        if check_range and self.precision == "f16x3":
+            scenes = list(scenes)
+            self.f16_range_exceeded(clear=True)
+            outs = self.predict_many(scenes, fold_head, return_logits, return_features, net_streams)
+            if not self.f16_range_exceeded(clear=True):
+                return outs
+            return self._bf16x6_twin().predict_many(scenes, fold_head, return_logits, return_features, net_streams)
         with torch.cuda.device(self.device), torch.no_grad():
             main = torch.cuda.current_stream()
-            side = self.__dict__.get("_side_stream")
-            if side is None:
-                side = self._side_stream = torch.cuda.Stream(device=self.device)
+            # one set of streams per device, shared by all engines: a process has few hardware queues (4 by default),
+            # and streams beyond them share a queue with another stream and stop overlapping with it
+            pool = _PIPE_STREAMS.setdefault(self.device.index if self.device.index is not None
+                                            else torch.cuda.current_device(), [])
+            while len(pool) < net_streams:
+                pool.append(torch.cuda.Stream(device=self.device))
+            side = pool[0]
             side.wait_stream(main)  # the inputs are ready where the caller's stream stands now
             nets = [main]
-            pool = self.__dict__.setdefault("_net_streams", [])
-            while len(pool) < net_streams - 1:
-                pool.append(torch.cuda.Stream(device=self.device))
-            for extra in pool[:max(0, net_streams - 1)]:
+            for extra in pool[1:max(1, net_streams)]:
                 extra.wait_stream(main)
                 nets.append(extra)
 

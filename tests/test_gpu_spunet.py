@@ -76,6 +76,9 @@ def test_f16_pairs_outside_their_range_are_detected_and_redone(device, case):
     assert out["precision"] == "bf16x6"
     assert _rel_rows(out["voxel_feat"], case["ref"]) < 1e-4
     assert (out["pred"].cpu() == ref_pred).float().mean().item() >= 0.999
+    # the same for a sequence of scenes
+    many = eng.predict_many([(coord, feat, b["offset"], 0.02)] * 2, check_range=True, net_streams=2)
+    assert all((m["pred"].cpu() == ref_pred).float().mean().item() >= 0.999 for m in many)
 
 
 def test_f16_pairs_match_the_oracle_at_f32_level(device):
