@@ -421,7 +421,12 @@ int m3d_avgpool_fwd(const float* d_in, int c, const int32_t* d_pair, int k, int6
 /* The fused head for `terms` = 2 (the entry points above) or 3 (M3D_PREC_BF16X6 products, leading and small
  * products accumulated separately): d_in_split, d_w1 (m3d_conv_pack_weight with M3D_PREC_BF16X6) and the packed text
  * are in the split format of that term count ([..][C/16][3][16] bf16 for three terms).  Same shapes supported, same
- * outputs, same reference call sites as m3d_head_fused_sf32. */
+ * outputs, same reference call sites as m3d_head_fused_sf32.
+ * `terms` = M3D_FMT_F16_PAIR: the two-term kernel on f16 pairs.  d_in_split and d_w1 are in the pair format of the
+ * convolutions (second term scaled by 2^11; d_w1 from m3d_conv_pack_weight with M3D_PREC_F16X3, any power-of-two
+ * factor of the weight undone through d_scale); the features are exact to 2^-22 and checked against the f16 range
+ * (m3d_f16_status); the text matrix (m3d_head_pack_text_terms with terms = 4) and the feature tile keep an unscaled
+ * second term, because the logits only feed the argmax and take a single accumulator (logits good to ~1e-5). */
 size_t m3d_head_text_bytes_terms(int classes_padded, int cmid, int terms);
 int m3d_head_pack_text_terms(const float* d_text, int n_classes, int cmid, int classes_padded, int terms, void* d_out,
                              void* stream);
