@@ -142,3 +142,51 @@ def test_modules_run_with_and_without_gradients(device, case):
         y = conv(x)                        # inference kernels
     assert y.features.shape == (2, 32) and "k" in x.indice_dict and not y.features.requires_grad
     assert torch.allclose(y.features, y_train.features.detach(), rtol=1e-5, atol=1e-6)
+
+
+def test_f16_pairs_on_a_network_with_calibrated_norms(device):
+    """A stand-in for a trained checkpoint: random affine pairs and context modulation in every PDNorm, running
+    statistics set by one training-mode pass over a scene (momentum 1), so that the eval-mode activations are
+    normalised layer by layer as training leaves them.  Precision "f16x3" must then stay inside the f16 range and
+    match the float64 CPU oracle as closely as bf16x6 does (both far inside 1e-4), on another scene."""
+    cfg = ospunet.SPUNET34C
+    torch.manual_seed(7)
+    model = spunet.PPT(spunet.SpUNet(**{k: cfg[k] for k in ("in_channels", "out_channels", "base_channels",
+                                                             "context_channels", "channels", "layers", "conditions")},
+                                     zero_init=False), cfg["conditions"], cfg["context_channels"]).to(device)
+    with torch.no_grad():
+        for m in model.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.uniform_(-0.5, 0.5)
+                m.momentum = 1.0
+            elif isinstance(m, spunet.PDBatchNorm) and m.adaptive:
+                m.modulation[-1].weight.normal_(std=0.02)
+                m.modulation[-1].bias.normal_(std=0.1)
+    cal = scenes.make_batch([31], target_voxels=20000)
+    batch = dict(coord=torch.from_numpy(cal["coord"]).to(device), feat=torch.from_numpy(cal["feat"]).to(device),
+                 offset=torch.as_tensor(cal["offset"]), grid_size=0.02, condition=["ScanNet"])
+    model.train()
+    with torch.no_grad():
+        model(batch)
+    model.eval()
+    P = {(k[len("backbone."):] if k.startswith("backbone.") else k): (v.detach().cpu().double() if v.is_floating_point()
+                                                                       else v.detach().cpu())
+         for k, v in model.state_dict().items()}
+    b = scenes.make_batch([32], target_voxels=20000)
+    sp = oracle.sparsify(b["coord"], b["feat"], b["offset"], 0.02)
+    ref, inter = ospunet.spunet_forward(P, cfg, torch.from_numpy(sp["voxel_feats"]), sp["voxel_coords"],
+                                        sp["spatial_shape"], "ScanNet", return_intermediates=True, dtype=torch.float64)
+    amax = max(float(v.abs().max()) for v in inter.values())
+    assert 0.5 < amax < 1e3, amax  # normalised activations, as in a trained network
+    coord, feat = torch.from_numpy(b["coord"]).to(device), torch.from_numpy(b["feat"]).to(device)
+    errs = {}
+    for prec in ("f16x3", "bf16x6"):
+        eng = SpUNetEngine(model, cfg, "ScanNet", device, precision=prec)
+        eng.f16_range_exceeded(clear=True)
+        feats, vox = eng.forward_features(coord, feat, b["offset"], 0.02)
+        errs[prec] = _rel_rows(feats, ref)
+        assert eng.f16_range_exceeded(clear=True) is False
+    # measured: bf16x6 2.0e-6, f16x3 2.6e-6 (the worst voxel of this network has features that nearly cancel)
+    assert errs["f16x3"] < 1e-5 and errs["bf16x6"] < 1e-5, errs
+    assert errs["f16x3"] < 2 * errs["bf16x6"] + 1e-7, errs
