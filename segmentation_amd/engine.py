@@ -404,10 +404,11 @@ class SpUNetEngine:
                     with torch.cuda.stream(net):
                         out = self._predict(None, None, None, None, fold_head, return_logits, return_features,
                                             maps=(vox, levels, n_points))
-                    if net is not main:  # the caller will use (and free) these on its own stream
-                        for v in out.values():
-                            if torch.is_tensor(v):
-                                v.record_stream(main)
+                    # the caller will use (and free) the results on its own stream; some were allocated on the side
+                    # stream (v2p_map) or on a second network stream
+                    for v in out.values():
+                        if torch.is_tensor(v) and v.is_cuda:
+                            v.record_stream(main)
                     outs.append(out)
                     # memory handed out on the side stream must outlive its use on the network's stream: the scene's
                     # maps are released only when the work enqueued up to here has finished
