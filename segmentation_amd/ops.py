@@ -21,8 +21,14 @@ _workspaces = {}
 PROFILE = None
 
 
+def _raw_stream() -> int:
+    """Handle of the current stream of the current device.  (torch.cuda.current_stream() builds a Stream object and
+    re-validates the device on every call: a quarter of the host time of a scene before this replaced it.)"""
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
+
+
 def _stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return ctypes.c_void_p(_raw_stream())
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -32,7 +38,7 @@ def _ptr(t: Optional[torch.Tensor]):
 def _workspace(nbytes: int, device) -> torch.Tensor:
     """One growing scratch buffer per (device, stream); kernels on a stream run in order, so
     consecutive calls may share it."""
-    key = (torch.device(device).index, torch.cuda.current_stream().cuda_stream)
+    key = ((device if isinstance(device, torch.device) else torch.device(device)).index, _raw_stream())
     ws = _workspaces.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(max(int(nbytes * 1.25), 1 << 20), dtype=torch.uint8, device=device)
@@ -48,7 +54,7 @@ def _need_cuda(*ts):
         if not t.is_cuda:
             raise RuntimeError("segmentation_amd operators need tensors on an AMD GPU (cuda device); "
                                "there is no CPU path")
-        if t.device.index != torch.cuda.current_device():
+        if t.device.index != torch._C._cuda_getDevice():
             raise RuntimeError(f"tensor on {t.device} but the current device is cuda:{torch.cuda.current_device()}: "
                                "run under `with torch.cuda.device(tensor.device):` (one process per GPU is the "
                                "intended deployment)")
