@@ -23,7 +23,8 @@ from . import ops
 
 
 # How the sparse-convolution modules form their f32 products: "f32" (exact, v_mfma_f32_32x32x2_f32),
-# "bf16x6" (3-term bf16 split, f32-level accuracy) or "bf16x3" (2-term split, ~1e-5 relative).
+# "bf16x6" (3-term bf16 split, f32-level accuracy), "bf16x3" (2-term split, ~1e-5 relative), "bf16", or "f16x3"
+# (f16 pairs, f32-level accuracy inside the f16 range; inference only: gradients underflow that range unnoticed).
 _PRECISION = "f32"
 
 
@@ -312,6 +313,9 @@ class _SparseConvFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, feats, weight, bias, sched_fwd, sched_back, n_out, n_in, flip):
+        if _PRECISION == "f16x3":
+            raise ValueError('precision "f16x3" is for inference: gradients are far smaller than the f16 range '
+                             'resolves and the range check only sees overflow; train with "bf16x3", "bf16x6" or "f32"')
         feats = feats.contiguous()
         w = ops.pack_weight(weight.detach(), _PRECISION)
         out = ops.conv_fwd(_maybe_split(feats, w), w, sched_fwd, n_out,

@@ -109,6 +109,22 @@ def test_backward_with_split_bf16_products(device, level, cin, cout):
     assert max(errs) < 5e-5, errs
 
 
+def test_f16_pairs_are_refused_for_training(device):
+    conv = sparse.SubMConv3d(32, 32, 1, bias=False).to(device)
+    x = sparse.SparseConvTensor(torch.randn(100, 32, device=device, requires_grad=True),
+                                torch.zeros((100, 4), dtype=torch.int32, device=device), [8, 8, 8], 1)
+    sparse.set_precision("f16x3")
+    try:
+        with pytest.raises(ValueError):
+            conv(x)
+        with torch.no_grad():  # inference through the modules is fine
+            y = conv(x).features
+        ref = x.features.detach() @ conv.weight.detach().reshape(32, 32).T
+        assert ((y - ref).norm() / ref.norm()).item() < 1e-6
+    finally:
+        sparse.set_precision("f32")
+
+
 def test_conv1x1_backward(device):
     g = torch.Generator().manual_seed(4)
     x = torch.randn(3000, 96, generator=g)
