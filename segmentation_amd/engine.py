@@ -19,6 +19,7 @@ from typing import Dict, Optional, Sequence
 
 import collections
 import os
+import time
 import torch
 
 from . import ops, sparse
@@ -45,6 +46,28 @@ def _fold_norm(sd: Dict[str, torch.Tensor], prefix: str, cond_idx: int, context:
 
 
 _PIPE_STREAMS = {}  # device index -> [side stream, extra network streams ...] of predict_many
+
+
+def _tensors_of(obj, seen=None, cuda_only=True):
+    """Every (CUDA) tensor reachable from obj through lists, tuples, dicts and the attributes of plain objects,
+    `__slots__` classes included (each tensor once)."""
+    seen = set() if seen is None else seen
+    if torch.is_tensor(obj):
+        if (obj.is_cuda or not cuda_only) and id(obj) not in seen:
+            seen.add(id(obj))
+            yield obj
+    elif isinstance(obj, (list, tuple)):
+        for v in obj:
+            yield from _tensors_of(v, seen, cuda_only)
+    elif isinstance(obj, dict):
+        for v in obj.values():
+            yield from _tensors_of(v, seen, cuda_only)
+    elif (hasattr(obj, "__dict__") or hasattr(obj, "__slots__")) and id(obj) not in seen:
+        seen.add(id(obj))
+        names = list(getattr(obj, "__dict__", {})) + [n for c in type(obj).__mro__ for n in getattr(c, "__slots__", ())]
+        for name in names:
+            if hasattr(obj, name):
+                yield from _tensors_of(getattr(obj, name), seen, cuda_only)
 
 
 class _Conv:
@@ -75,6 +98,7 @@ class SpUNetEngine:
         sd = {k: v.detach().to("cpu") for k, v in sd.items()}
         self._state = sd        # kept for the wider-range twin that predict_checked falls back to
         self._twin = None
+        self.pipe_log = None  # list: predict_many appends its host times per scene (diagnostics)
         self._emb = None
         self.cfg = cfg
         self.precision = precision
@@ -392,7 +416,7 @@ class SpUNetEngine:
                     ready.record(side)
                 return int(coord.shape[0]), vox, levels, ready
 
-            outs, alive = [], collections.deque()
+            outs, inflight = [], collections.deque()
             it = iter(scenes)
             nxt = next(it, None)
             cur = first_stage(nxt) if nxt is not None else None
@@ -401,28 +425,45 @@ class SpUNetEngine:
                     n_points, vox, levels, ready = cur
                     net = nets[len(outs) % len(nets)]
                     net.wait_event(ready)
+                    t_a = time.perf_counter()
                     with torch.cuda.stream(net):
+                        if self.pipe_log is not None:
+                            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                            ev0.record()
                         out = self._predict(None, None, None, None, fold_head, return_logits, return_features,
                                             maps=(vox, levels, n_points))
+                        if self.pipe_log is not None:
+                            ev1.record()
+                    t_b = time.perf_counter()
                     # the caller will use (and free) the results on its own stream; some were allocated on the side
                     # stream (v2p_map) or on a second network stream
                     for v in out.values():
                         if torch.is_tensor(v) and v.is_cuda:
                             v.record_stream(main)
                     outs.append(out)
-                    # memory handed out on the side stream must outlive its use on the network's stream: the scene's
-                    # maps are released only when the work enqueued up to here has finished
+                    # memory handed out on the side stream must outlive its use on the network's stream: every map
+                    # tensor is marked as used there, so the allocator hands its block out again only after the work
+                    # enqueued up to here has finished (no host wait: a wait here is time in which the next network
+                    # is not being enqueued)
+                    marked = 0
+                    for t in _tensors_of((vox, levels)):
+                        t.record_stream(net)
+                        marked += 1
+                    # at least the coordinates, the submanifold map and its schedule of every level
+                    assert marked >= 5 * len(levels), "map tensors of a scene not found: they would be released early"
+                    # bounded run-ahead: the host may be several scenes ahead of the GPU (their maps are held until the
+                    # GPU is done with them), never more than eight
                     done = torch.cuda.Event()
                     done.record(net)
-                    alive.append((done, vox, levels))
+                    inflight.append(done)
+                    if len(inflight) > 8:
+                        inflight.popleft().synchronize()
                     nxt = next(it, None)
                     cur = first_stage(nxt) if nxt is not None else None
-                    while len(alive) > 2 * len(nets):
-                        alive.popleft()[0].synchronize()
+                    if self.pipe_log is not None:  # host seconds: network enqueue, first stage of the next scene
+                        self.pipe_log.append((t_b - t_a, time.perf_counter() - t_b, ev0, ev1))
             finally:
                 side.synchronize()
-                for done, _, _ in alive:
-                    done.synchronize()
                 for net in nets[1:]:
                     main.wait_stream(net)
             return outs

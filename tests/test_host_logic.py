@@ -118,3 +118,19 @@ def test_pred_record_and_label_ply_round_trip(tmp_path):
     assert np.array_equal(v["x"], coord.numpy()[:, 0])
     cm = export.class_colormap(int(lab.max()) + 1, 3)
     assert np.array_equal(v["r"], (cm[lab, 0] * 255).astype(np.uint8))
+
+
+def test_tensor_walker_reaches_slots_dataclasses_and_containers():
+    """predict_many marks every map tensor of a scene as used on the network's stream before letting go of it; a
+    tensor the walker misses would be handed out again while kernels still read it."""
+    import torch
+    from segmentation_amd import engine, ops
+    lv = engine._Level()                      # a __slots__ class
+    lv.indices, lv.shape, lv.n = torch.zeros(3), [1, 2, 3], 3
+    lv.subm = ops.Schedule(torch.zeros(2), torch.zeros(2), torch.zeros(2), 1, 256, 27)   # a dataclass
+    lv.subm.tile_order = torch.zeros(1)
+    lv.pair_fwd = lv.indices                  # the same tensor twice: reported once
+    vox = {"voxel_coords": torch.zeros(4), "spatial_shape": [4, 4, 4], "nested": (torch.zeros(1), [torch.zeros(1)])}
+    got = list(engine._tensors_of((vox, [lv]), cuda_only=False))
+    assert len(got) == 8 and len({id(t) for t in got}) == 8
+    assert list(engine._tensors_of((vox, [lv]))) == []   # CPU tensors are not stream-managed
