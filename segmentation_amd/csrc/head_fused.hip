@@ -412,46 +412,25 @@ static int launch_head(const HeadArgs& a, hipStream_t stream) {
 // The same head for three-term operands (M3D_PREC_BF16X6: f32-level products).  Activations, W1 and the text matrix
 // arrive in the three-term split format with 16-channel groups ([..][C/16][3][16] bf16), so a stage of 32 features
 // is, per feature, G1 = cin/16 rows of 96 bytes of W1 and, per class, two rows of 96 bytes of the text matrix; LDS
-// rows are 96 bytes with the pair swizzle of DmaGeom<3>.  Four waves x 32 voxel rows per workgroup, one wave per
-// SIMD (activation fragments, logits accumulators and operand terms need about 260 registers), two LDS buffers, one
-// barrier per stage: the DMA of stage s + 1 is requested right after the barrier that publishes stage s.  The
+// rows are 96 bytes with the pair swizzle of DmaGeom<3>.  Eight waves per workgroup in two roles: waves 0-3 own 32
+// voxel rows each and do nothing but read fragments and multiply (activation fragments, logits accumulators and
+// operand terms need about 250 registers); waves 4-7 do nothing but request the next stage's 61 KB (15 DMA
+// instructions each).  A wave issues in order and a DMA instruction holds it for 100-200 cycles, so with both jobs in
+// one wave the matrix pipe of its SIMD stood idle for a third of every stage; apart, the requests of stage s + 1
+// (about 2 500 cycles of issue per loader wave) hide under the 120 matrix instructions (3 840 cycles) of stage s.
+// Two LDS buffers, one barrier per stage: a loader waits for its own requests of stage s (vmcnt) before the barrier
+// that publishes them, and requests stage s + 1 right after it, when every matrix wave has left stage s - 1.  The
 // features accumulate leading and small products separately, as the convolution kernel does; the logits, which only
 // feed the argmax, use one accumulator per class tile.
+// The loader role of head_fused3_body: waves 4-7 of the workgroup (`wave` = 0..3 among them, tid = wave * 64 + lane).
 template <int G1, int NT2>
-__device__ __forceinline__ void head_fused3_body(const HeadArgs& a) {
+__device__ __forceinline__ void head_fused3_loader(const HeadArgs& a, char* ldsb, int wave, int tid, int nstage, int ngrp) {
   using G = DmaGeom<3>;
-  constexpr int NTHR = 256, ROWS = 128;
+  constexpr int NTHR = 256;
   constexpr int W1_ROWS = 32 * G1, W2_ROWS = 2 * NT2 * 32;
-  constexpr int W1_BYTES = W1_ROWS * G::ROWB, BUF = (W1_ROWS + W2_ROWS) * G::ROWB;
+  constexpr int BUF = (W1_ROWS + W2_ROWS) * G::ROWB;
   constexpr int W1_SLOTS = W1_ROWS * G::SLOTS, SLOTS = W1_SLOTS + W2_ROWS * G::SLOTS;
   constexpr int GI = (SLOTS + NTHR - 1) / NTHR;
-  static_assert(W1_BYTES % 256 == 0 && BUF % 256 == 0, "images start on a bank line");
-  extern __shared__ __align__(16) char ldsb[];
-  float* aff_s = reinterpret_cast<float*>(ldsb + 2 * BUF);  // [2][kHeadMaxFeatures]: scale, shift
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int r32 = lane & 31, h = lane >> 5;
-  const int64_t tile_base = (int64_t)blockIdx.x * ROWS;
-  const int nstage = a.cmid >> 5;
-  const int ngrp = a.cmid >> 4;  // 16-feature groups of the text matrix
-  const uint32_t lds_base = (uint32_t)(uintptr_t)(lds_ptr_t)ldsb;
-
-  // activation fragments of this wave's 32 rows: [channel group][term], 8 channels per lane
-  bf16x8 xf[G1][3];
-  {
-    const int64_t row = tile_base + wave * 32 + r32;
-    const char* xp = a.x + (row < a.n ? row : a.n) * (int64_t)(G1 * 96);
-#pragma unroll
-    for (int g = 0; g < G1; ++g)
-#pragma unroll
-      for (int t = 0; t < 3; ++t) xf[g][t] = *reinterpret_cast<const bf16x8*>(xp + g * 96 + t * 32 + h * 16);
-  }
-  for (int i = tid; i < a.cmid; i += NTHR) {
-    aff_s[i] = a.scale ? a.scale[i] : 1.f;
-    aff_s[kHeadMaxFeatures + i] = a.shift ? a.shift[i] : 0.f;
-  }
-
   // DMA addressing (loop invariant): slot e = v * NTHR + tid of a buffer is (image row e / 6, physical slot e % 6)
   // and carries logical piece (e % 6) ^ swz(row).  W1 image rows: group * 32 + feature; text image rows:
   // (k-step * NT2 + class tile) * 32 + class.
@@ -486,6 +465,57 @@ __device__ __forceinline__ void head_fused3_body(const HeadArgs& a) {
       }
   };
 
+  issue(0, 0);
+  for (int s = 0; s < nstage; ++s) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of stage s is in LDS
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (s + 1 < nstage) issue(s + 1, (s + 1) & 1);
+  }
+}
+
+template <int G1, int NT2>
+__device__ __forceinline__ void head_fused3_body(const HeadArgs& a) {
+  using G = DmaGeom<3>;
+  constexpr int NTHR = 256, ROWS = 128;  // NTHR: threads of one role (four waves)
+  constexpr int W1_ROWS = 32 * G1, W2_ROWS = 2 * NT2 * 32;
+  constexpr int W1_BYTES = W1_ROWS * G::ROWB, BUF = (W1_ROWS + W2_ROWS) * G::ROWB;
+  static_assert(W1_BYTES % 256 == 0 && BUF % 256 == 0, "images start on a bank line");
+  extern __shared__ __align__(16) char ldsb[];
+  float* aff_s = reinterpret_cast<float*>(ldsb + 2 * BUF);  // [2][kHeadMaxFeatures]: scale, shift
+
+  const int lane = threadIdx.x & 63;
+  const int wave_all = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const bool loader = wave_all >= 4;
+  const int wave = wave_all & 3;          // index inside the role
+  const int tid = wave * 64 + lane;
+  const int r32 = lane & 31, h = lane >> 5;
+  const int64_t tile_base = (int64_t)blockIdx.x * ROWS;
+  const int nstage = a.cmid >> 5;
+  const int ngrp = a.cmid >> 4;  // 16-feature groups of the text matrix
+  const uint32_t lds_base = (uint32_t)(uintptr_t)(lds_ptr_t)ldsb;
+
+  for (int i = threadIdx.x; i < a.cmid; i += 2 * NTHR) {  // published by the first stage barrier
+    aff_s[i] = a.scale ? a.scale[i] : 1.f;
+    aff_s[kHeadMaxFeatures + i] = a.shift ? a.shift[i] : 0.f;
+  }
+
+  if (loader) {
+    head_fused3_loader<G1, NT2>(a, ldsb, wave, tid, nstage, ngrp);
+    return;  // nothing after the stage loop needs a barrier
+  }
+
+  // activation fragments of this wave's 32 rows: [channel group][term], 8 channels per lane
+  bf16x8 xf[G1][3];
+  {
+    const int64_t row = tile_base + wave * 32 + r32;
+    const char* xp = a.x + (row < a.n ? row : a.n) * (int64_t)(G1 * 96);
+#pragma unroll
+    for (int g = 0; g < G1; ++g)
+#pragma unroll
+      for (int t = 0; t < 3; ++t) xf[g][t] = *reinterpret_cast<const bf16x8*>(xp + g * 96 + t * 32 + h * 16);
+  }
+
   // fragment read offsets inside an image: piece 2 t + h of row (.. + r32); the swizzle depends on r32 only because
   // every image row base is a multiple of 32 rows
   uint32_t frag[3];
@@ -498,13 +528,11 @@ __device__ __forceinline__ void head_fused3_body(const HeadArgs& a) {
 #pragma unroll
     for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
 
-  issue(0, 0);
   for (int s = 0; s < nstage; ++s) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the activation fragments (first stage only)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();  // stage s has landed for every wave; every wave is done with stage s - 1
+    __builtin_amdgcn_s_barrier();  // stage s has landed (the loaders waited for it); every wave is done with stage s - 1
     asm volatile("" ::: "memory");
-    if (s + 1 < nstage) issue(s + 1, (s + 1) & 1);
 
     // A: F^T tile (features x rows) = W1 tile . X^T, six products per channel group.  The three fragment reads of a
     // step are issued by hand (lds_read16) one step ahead of the products that consume them and waited for with a
@@ -613,7 +641,7 @@ __device__ __forceinline__ void head_fused3_body(const HeadArgs& a) {
 }
 
 template <int G1, int NT2>
-__global__ __launch_bounds__(256) void head_fused3_kernel(HeadArgs a) {
+__global__ __launch_bounds__(512) void head_fused3_kernel(HeadArgs a) {
   head_fused3_body<G1, NT2>(a);
 }
 
@@ -624,7 +652,7 @@ static int launch_head3(const HeadArgs& a, hipStream_t stream) {
   static_assert(lds <= 160 * 1024, "LDS budget");
   static LdsGrant grant;
   if (int rc = grant.ensure(reinterpret_cast<const void*>(&head_fused3_kernel<G1, NT2>), lds)) return rc;
-  hipLaunchKernelGGL((head_fused3_kernel<G1, NT2>), dim3((unsigned)cdiv(a.n, 128)), dim3(256), lds, stream, a);
+  hipLaunchKernelGGL((head_fused3_kernel<G1, NT2>), dim3((unsigned)cdiv(a.n, 128)), dim3(512), lds, stream, a);
   M3D_LAUNCH_CHECK();
   return M3D_OK;
 }
