@@ -378,6 +378,10 @@ __device__ unsigned long long m3d_stamp_sums[8];
 #define M3D_T(var) unsigned long long var; __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); __builtin_amdgcn_sched_barrier(0)
 #endif
 
+// Size the buffer descriptors of the LDS-DMA kernel claim for every operand: per-lane offsets from here up are out of
+// range (the request returns zeros), everything an operand holds must lie below.
+constexpr uint32_t kDmaBufferBytes = 0xFFFFFF00u;
+
 struct UnitIt {  // position in the unit sequence of a tile: kernel offset k (lowest set bit of rem), channel group cc
   uint32_t rem;
   int k, cc;
@@ -419,6 +423,21 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvArgs& a) {
   const int g0 = a.c0 / G::G;
   const char* wsplit = reinterpret_cast<const char*>(a.weight);
   const uint32_t rowb0 = (uint32_t)g0 * GRPA, rowb1 = (uint32_t)(a.c1 / G::G) * GRPA;
+  // Buffer addressing of the stage requests (split activations, one unit per stage): a request is
+  // `buffer_load_dwordx4 ... offen lds` with a 32-bit per-lane byte offset that only changes with the kernel offset
+  // (gathered row * row bytes + piece) and a scalar offset that carries the channel group of the stage, so a stage
+  // spends no vector instruction on addresses (with 64-bit per-lane addresses it spent three per request, and the
+  // request itself cost its wave more).  A missing neighbour gets an offset beyond the buffer's size: the hardware
+  // then writes zeros to LDS without a memory request.  Operands are limited to kDmaBufferBytes (checked by the host).
+  constexpr bool BUFA = !AF && UPS == 1;
+  constexpr int kRsrcWord3 = 0x00020000;  // raw buffer, 32-bit elements
+  const __amdgpu_buffer_rsrc_t rs0 =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(a.s0), (short)0, (int)kDmaBufferBytes, kRsrcWord3);
+  const __amdgpu_buffer_rsrc_t rs1 =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(a.s1 ? a.s1 : a.s0), (short)0, (int)kDmaBufferBytes, kRsrcWord3);
+  const __amdgpu_buffer_rsrc_t rsw =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(wsplit), (short)0, (int)kDmaBufferBytes, kRsrcWord3);
+  uint32_t a_vo0[A_V], a_vo1[A_V];
 
   uint32_t bmask, wmask;
   conv_masks<WM>(a, tile_base, wm, bmask, wmask);
@@ -491,6 +510,13 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvArgs& a) {
     if (UPS == 2) step(n1);
 #pragma unroll
     for (int v = 0; v < A_V; ++v) a_id[v] = idx_s[(a_u[v] ? n1.k : it.k) * BM + a_r[v]];
+    if constexpr (BUFA) {
+#pragma unroll
+      for (int v = 0; v < A_V; ++v) {
+        a_vo0[v] = a_id[v] < 0 ? kDmaBufferBytes : (uint32_t)a_id[v] * rowb0 + a_p[v];
+        a_vo1[v] = a_id[v] < 0 ? kDmaBufferBytes : (uint32_t)a_id[v] * rowb1 + a_p[v];
+      }
+    }
   };
   load_ids();
   // DMA instructions this wave issues per stage (the same for every stage): the counted waits below depend on it
@@ -501,6 +527,37 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvArgs& a) {
   for (int v = 0; v < W_V; ++v) gw += (v * NTHR + wave * 64 < BN * G::SLOTS) ? 1 : 0;
   auto issue_next = [&](int bi) {
     char* buf = ldsb + bi * BUF;
+    if constexpr (BUFA) {
+      const int k_before = it.k;
+      const bool first = it.cc < g0;
+      const uint32_t soff_a = (uint32_t)(first ? it.cc : it.cc - g0) * GRPA;
+      const uint32_t soff_w = (uint32_t)it.k * wk_stride + (uint32_t)it.cc * GRPB;
+      step(it);
+      ++issued;
+      if (first) {
+#pragma unroll
+        for (int v = 0; v < A_V; ++v)
+          if (A_EXACT || v * NTHR + wave * 64 < BM * GA::SLOTS)
+            if ((A_EXACT && NO_DEAD) || a_on[v])
+              __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (lds_ptr_t)(buf + (v * NTHR + wave * 64) * 16), 16, a_vo0[v],
+                                                       soff_a, 0, 0);
+      } else {
+#pragma unroll
+        for (int v = 0; v < A_V; ++v)
+          if (A_EXACT || v * NTHR + wave * 64 < BM * GA::SLOTS)
+            if ((A_EXACT && NO_DEAD) || a_on[v])
+              __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (lds_ptr_t)(buf + (v * NTHR + wave * 64) * 16), 16, a_vo1[v],
+                                                       soff_a, 0, 0);
+      }
+#pragma unroll
+      for (int v = 0; v < W_V; ++v)
+        if (W_EXACT || v * NTHR + wave * 64 < BN * G::SLOTS)
+          if ((W_EXACT && NO_DEAD) || w_on[v])
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr_t)(buf + A_BYTES + (v * NTHR + wave * 64) * 16), 16,
+                                                     w_o[v], soff_w, 0, 0);
+      if (issued < nunit && it.k != k_before) load_ids();
+      return;
+    }
     const char* src[UPS];
     const char* wsrc[UPS];
     uint32_t rowb[UPS];
@@ -1272,6 +1329,13 @@ extern "C" int m3d_conv_fwd_sf32(const void* d_in0, int c0, int64_t rows0, const
   M3D_CHECK_ARG(c0 % 32 == 0 && c1 % 32 == 0 && cout % 32 == 0, "%s: channel counts must be multiples of 32", who);
   M3D_CHECK_ARG((c1 == 0) == (d_in1 == nullptr), "%s: in1/c1 mismatch", who);
   M3D_CHECK_ARG(rows0 >= 0 && rows1 >= 0, "%s: negative row count", who);
+  {  // the kernel addresses every operand with 32-bit byte offsets inside one buffer descriptor
+    const int64_t bpc = 2 * split_nterms(terms);  // bytes per channel of a split row
+    const int64_t cmax = c0 > c1 ? c0 : c1, rmax = rows0 > rows1 ? rows0 : rows1;
+    M3D_CHECK_ARG((rmax + 1) * cmax * bpc <= (int64_t)kDmaBufferBytes && (int64_t)k * cout * (c0 + c1) * bpc <= (int64_t)kDmaBufferBytes,
+                  "%s: an operand of more than 4 GB (%lld rows x %lld channels x %lld bytes) is beyond the kernel's buffer addressing",
+                  who, (long long)rmax, (long long)cmax, (long long)bpc);
+  }
   M3D_CHECK_ARG(d_out == nullptr || ldo >= cout, "%s: ldo < cout", who);
   if (int rc = check_schedule(d_nbr, d_out_row, d_tile_mask, k, n, &npad, who)) return rc;
   M3D_CHECK_ARG(d_nbr != nullptr || rows0 >= n, "%s: dense mode needs rows0 >= n", who);
