@@ -243,7 +243,11 @@ int m3d_conv_fwd_f32(const float* d_in0, int c0, const float* d_in1, int c1,
 /* Same convolution with the activations in the engine-internal split format "sf32":
  *   [rows + 1][C/G][terms][G] bf16 with G = 16 channels per group for terms = 3 and 32 otherwise (terms = 1 is plain
  *   row-major bf16), term t = bf16 rounding of what terms < t left over, row `rows` all zero (missing neighbours
- *   gather it).  Inputs are moved to LDS by per-lane-addressed LDS-DMA (global_load_lds_dwordx4); products as in
+ *   gather it).  Inputs are moved to LDS by LDS-DMA: with two or three terms and the f16 pair the requests are
+ *   buffer loads (buffer_load_dwordx4 ... offen lds: 32-bit per-lane byte offsets inside one descriptor per operand,
+ *   a missing neighbour is an out-of-range offset, which the hardware answers with zeros), so every operand --
+ *   (rows + 1) rows of either input, the packed weights -- must stay below 4 GB, else M3D_EINVAL; with one term they
+ *   carry 64-bit per-lane addresses (global_load_lds_dwordx4) and the missing neighbours gather the zero row.  Products as in
  *   M3D_PREC_BF16 (terms = 1) / M3D_PREC_BF16X3 (terms = 2) / M3D_PREC_BF16X6 (terms = 3; the leading products and
  *   the small ones are accumulated separately and added once at the end).
  *   d_tile_order: NULL or m3d_schedule_tile_order's output for this schedule.

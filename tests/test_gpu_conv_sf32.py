@@ -200,3 +200,20 @@ def test_f16_status_reports_values_beyond_the_f16_range(device):
     big = torch.full((300, 64), 50.0, device=device)
     ops.conv_fwd(ops.split_f32(big, 4), w, None, 300, split_terms=4)
     assert ops.f16_status(clear=True) is True
+
+
+def test_operands_beyond_the_buffer_addressing_are_refused(device, level):
+    """The kernel addresses an operand with 32-bit byte offsets inside one buffer descriptor: a row count that would
+    put any row of a split tensor at or beyond 4 GB is an argument error, raised before anything is launched (the
+    tensor handed over here is small; only the declared row count is large)."""
+    from segmentation_amd import _lib
+    lv = level
+    n = lv["idx"].shape[0]
+    x = ops.split_f32(torch.randn(n, 96, device=device), 3)
+    w = ops.pack_weight(torch.randn(96, 27, 96) * 0.05, "bf16x6", device)
+    big = ops.SplitTensor(x.data, 8_000_000, 96, 3)   # 8 M rows x 96 channels x 6 bytes = 4.6 GB
+    with pytest.raises(_lib.M3DError, match="4 GB"):
+        ops.conv_fwd(big, w, lv["sched"], n)
+    out = ops.conv_fwd(x, w, lv["sched"], n)          # the same call with the true row count still runs
+    out = out[0] if isinstance(out, tuple) else out
+    assert torch.isfinite(out).all()
