@@ -216,11 +216,19 @@ class SpUNetEngine:
         row counts handed from level to level on the device and read back once (behind the level-0 map work); the
         submanifold maps and all schedules are enqueued without any further host read-back, so the host runs ahead
         of the GPU into the network."""
-        levels = []
+        return self.build_levels_begin(voxel_coords, spatial_shape, batch_size)()
+
+    def build_levels_begin(self, voxel_coords, spatial_shape, batch_size=1):
+        """First half of build_levels: enqueues the chain of strided maps and the level-0 map and schedule, and
+        returns the function that does the rest (it waits for the level counts, nothing else)."""
         chain_done = ops.strided_chain(voxel_coords, spatial_shape, batch_size, self.num_stages, defer=True)
         # level 0 needs nothing from the chain: its map and schedule keep the GPU busy while the counts travel
         pair0 = ops.subm_rulebook(voxel_coords, list(spatial_shape), batch_size)
         sched0 = self._subm_schedule(0, pair0, voxel_coords.shape[0], voxel_coords, list(spatial_shape), batch_size)
+        return lambda: self._build_levels_finish(voxel_coords, spatial_shape, batch_size, chain_done, pair0, sched0)
+
+    def _build_levels_finish(self, voxel_coords, spatial_shape, batch_size, chain_done, pair0, sched0):
+        levels = []
         chain = chain_done()
         idx, shape = voxel_coords, list(spatial_shape)
         for l in range(self.num_stages + 1):
@@ -408,21 +416,60 @@ class SpUNetEngine:
                 extra.wait_stream(main)
                 nets.append(extra)
 
-            def first_stage(sc):
-                coord, feat, offset, grid_size = sc
+            # The first stage of a scene in three host phases, all enqueued on the side stream: A the voxelizer, B (needs
+            # the voxel count) the chain of strided maps and the level-0 map, C (needs the level counts) the other maps;
+            # each phase's read-back waits for its own small copy only.  The host interleaves them with the network
+            # of an earlier scene, so that a read-back finds its result already there instead of idling:
+            #   A(i+2)  network(i)  B(i+2)  C(i+1)
+            class _Scene:
+                __slots__ = ("scene", "n_points", "phase", "fin", "vox", "levels", "ready")
+
+            pending = {}   # scene number -> _Scene
+            it = iter(scenes)
+            fetched = [0]
+
+            def advance(j, phase):
+                """Run the first-stage phases of scene j up to `phase` (1 = A, 2 = B, 3 = C); False past the end."""
+                while fetched[0] <= j:
+                    sc = next(it, None)
+                    if sc is None:
+                        return False
+                    st = _Scene()
+                    st.scene, st.n_points, st.phase, st.fin, st.vox, st.levels, st.ready = sc, 0, 0, None, None, None, None
+                    pending[fetched[0]] = st
+                    fetched[0] += 1
+                st = pending.get(j)
+                if st is None:
+                    return False
                 with torch.cuda.stream(side):
-                    vox, levels = self._voxelize_and_maps(coord, feat, offset, grid_size)
-                    ready = torch.cuda.Event()
-                    ready.record(side)
-                return int(coord.shape[0]), vox, levels, ready
+                    if st.phase < 1 <= phase:
+                        coord, feat, offset, grid_size = st.scene
+                        st.scene, st.n_points = None, int(coord.shape[0])
+                        st.fin = ops.voxelize(coord, feat, offset, grid_size, pad=128, defer=True)
+                        st.phase = 1
+                    if st.phase < 2 <= phase:
+                        st.vox = st.fin()
+                        st.fin = self.build_levels_begin(st.vox["voxel_coords"], st.vox["spatial_shape"],
+                                                         st.vox["batch_size"])
+                        st.phase = 2
+                    if st.phase < 3 <= phase:
+                        st.levels = st.fin()
+                        st.fin = None
+                        st.ready = torch.cuda.Event()
+                        st.ready.record(side)
+                        st.phase = 3
+                return True
 
             outs, inflight = [], collections.deque()
-            it = iter(scenes)
-            nxt = next(it, None)
-            cur = first_stage(nxt) if nxt is not None else None
             try:
-                while cur is not None:
-                    n_points, vox, levels, ready = cur
+                i = 0
+                advance(0, 3)
+                advance(1, 2)
+                while i in pending:
+                    advance(i + 2, 1)
+                    advance(i, 3)
+                    st = pending.pop(i)
+                    n_points, vox, levels, ready = st.n_points, st.vox, st.levels, st.ready
                     net = nets[len(outs) % len(nets)]
                     net.wait_event(ready)
                     t_a = time.perf_counter()
@@ -458,8 +505,9 @@ class SpUNetEngine:
                     inflight.append(done)
                     if len(inflight) > 8:
                         inflight.popleft().synchronize()
-                    nxt = next(it, None)
-                    cur = first_stage(nxt) if nxt is not None else None
+                    advance(i + 2, 2)
+                    advance(i + 1, 3)
+                    i += 1
                     if self.pipe_log is not None:  # host seconds: network enqueue, first stage of the next scene
                         self.pipe_log.append((t_b - t_a, time.perf_counter() - t_b, ev0, ev1))
             finally:

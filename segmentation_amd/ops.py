@@ -66,8 +66,11 @@ def _shape3(shape: Sequence[int]):
 
 
 # ----------------------------------------------------------------------------- voxelize
+_PINNED_META = {}
+
+
 def voxelize(coord, feat, offset, grid_size, pad=128, hash_method="fnv", grid_mode="div",
-             return_keys=False, return_grid_coord=False, pooling_method="mean", seed=0):
+             return_keys=False, return_grid_coord=False, pooling_method="mean", seed=0, defer=False):
     """Point.sparsify + mean_pooling / random_pooling on the GPU (reference: structure.py:197-251, :34-110).
 
     pooling_method="random" keeps the voxel set, order and v2p_map and takes every voxel's features from one of its
@@ -75,7 +78,10 @@ def voxelize(coord, feat, offset, grid_size, pad=128, hash_method="fnv", grid_mo
 
     offset: cumulative counts, with or without the leading 0 (misc.py:8-13), tensor or list.
     Returns a dict with voxel_coords [N0,4] i32, voxel_feats [N0,C] f32, v2p_map [N] i64,
-    spatial_shape (list of 3), batch_size, optional keys [N0] (uint64 bit patterns in int64)."""
+    spatial_shape (list of 3), batch_size, optional keys [N0] (uint64 bit patterns in int64).
+    defer=True: the kernels are enqueued, the output sizes travel to pinned host memory asynchronously, and a
+    function is returned that waits for that copy alone and yields the dict (mean pooling only): what the caller
+    enqueues in between keeps the host busy while the voxelizer runs."""
     lib = _lib.load()
     _need_cuda(coord, feat)
     coord = coord.contiguous().float()
@@ -110,15 +116,37 @@ def voxelize(coord, feat, offset, grid_size, pad=128, hash_method="fnv", grid_mo
                           HASH[hash_method], GRID[grid_mode], _ptr(voxel_coords), _ptr(voxel_feats),
                           _ptr(v2p), _ptr(keys), _ptr(gc), _ptr(meta), _ptr(ws), ws.numel(), _stream())
     _lib.check(rc, "m3d_voxelize")
-    m = meta.cpu().tolist()  # the one host sync of the voxelizer: output sizes are data dependent
-    n0 = m[0]
-    out = dict(voxel_coords=voxel_coords[:n0], voxel_feats=voxel_feats[:n0], v2p_map=v2p,
-               spatial_shape=[int(m[1]), int(m[2]), int(m[3])], batch_size=batch_size, n_voxels=n0,
-               grid_min=[int(m[4]), int(m[5]), int(m[6])])
-    if return_keys:
-        out["keys"] = keys[:n0]
-    if return_grid_coord:
-        out["grid_coord"] = gc
+
+    def result(m):
+        n0 = m[0]
+        out = dict(voxel_coords=voxel_coords[:n0], voxel_feats=voxel_feats[:n0], v2p_map=v2p,
+                   spatial_shape=[int(m[1]), int(m[2]), int(m[3])], batch_size=batch_size, n_voxels=n0,
+                   grid_min=[int(m[4]), int(m[5]), int(m[6])])
+        if return_keys:
+            out["keys"] = keys[:n0]
+        if return_grid_coord:
+            out["grid_coord"] = gc
+        return out
+
+    if defer:
+        if pooling_method != "mean":
+            raise ValueError("voxelize(defer=True) supports mean pooling only")
+        # one pinned buffer per call in flight: the caller may start the next scene before finishing this one
+        slot = _PINNED_META.setdefault(dev.index, [])
+        pinned = slot.pop() if slot else torch.empty((16,), dtype=torch.int64, pin_memory=True)
+        pinned.copy_(meta, non_blocking=True)
+        landed = torch.cuda.Event()
+        landed.record()
+
+        def finish():
+            landed.synchronize()
+            m = pinned.tolist()
+            slot.append(pinned)
+            return result(m)
+
+        return finish
+    out = result(meta.cpu().tolist())  # the one host sync of the voxelizer: output sizes are data dependent
+    n0 = out["n_voxels"]
     if pooling_method == "random":
         choice = torch.empty((n0,), dtype=torch.int64, device=dev)
         ws2 = _workspace(lib.m3d_voxel_pick_random_workspace_bytes(n0), dev)
@@ -193,16 +221,17 @@ def strided_chain(indices, spatial_shape, batch_size, depth, defer=False):
 
     if not defer:
         return slices(counts.cpu().tolist())  # the one host sync of the chain
-    pinned = _PINNED_COUNTS.get(depth)
-    if pinned is None:
-        pinned = _PINNED_COUNTS[depth] = torch.empty((depth,), dtype=torch.int64, pin_memory=True)
+    slot = _PINNED_COUNTS.setdefault((dev.index, depth), [])  # one pinned buffer per call in flight
+    pinned = slot.pop() if slot else torch.empty((depth,), dtype=torch.int64, pin_memory=True)
     pinned.copy_(counts, non_blocking=True)
     landed = torch.cuda.Event()
     landed.record()
 
     def finish():
         landed.synchronize()
-        return slices(pinned.tolist())
+        m = pinned.tolist()
+        slot.append(pinned)
+        return slices(m)
 
     return finish
 
