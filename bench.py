@@ -150,7 +150,7 @@ def main():
                     help="how products are formed: exact f32 MFMA, bf16 MFMA on 3-/2-term splits of f32, plain bf16")
     ap.add_argument("--fold-head", action="store_true", help="fold `final` into the text matrix (not the headline)")
     ap.add_argument("--no-variants", action="store_true", help="skip the measurements of the other precisions")
-    ap.add_argument("--net-streams", type=int, default=2,
+    ap.add_argument("--net-streams", type=int, default=3,
                     help="streams the networks of consecutive scenes are dealt to (predict_many); 1 = one network at a time")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="finish every scene before the next one starts (predict) instead of overlapping the map "
