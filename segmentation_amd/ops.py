@@ -103,7 +103,10 @@ def voxelize(coord, feat, offset, grid_size, pad=128, hash_method="fnv", grid_mo
     b = counts.numel()
     batch_size = int(torch.nonzero(counts > 0).max()) + 1
     dev = coord.device
-    off_d = off.to(dev)
+    # through pinned memory, asynchronously: a pageable copy would hold the host until the stream has caught up
+    off_pin = torch.empty(off.shape, dtype=torch.int64, pin_memory=True)
+    off_pin.copy_(off)
+    off_d = off_pin.to(dev, non_blocking=True)
     voxel_coords = torch.empty((n, 4), dtype=torch.int32, device=dev)
     voxel_feats = torch.empty((n, c), dtype=torch.float32, device=dev)
     v2p = torch.empty((n,), dtype=torch.int64, device=dev)
