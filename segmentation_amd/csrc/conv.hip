@@ -1122,7 +1122,8 @@ static ConvPlan plan_conv(int64_t npad, int cout, int kvol, int cin) {
   else bn = 32;
   const int64_t ncol = cout / bn;
   const int64_t target = 480, enough = 400;
-  const int max_nz = kvol == 27 ? 9 : 1;  // strided and inverse maps have about one active offset per output tile
+  static const int nz_cap = getenv("M3D_MAX_NZ") ? atoi(getenv("M3D_MAX_NZ")) : 9;
+  const int max_nz = kvol == 27 ? nz_cap : 1;  // strided and inverse maps have about one active offset per output tile
   for (int bm = cin >= 96 ? 128 : 64; bm >= 32; bm /= 2) {
     const int64_t blocks = (npad / bm) * ncol;
     if (blocks >= target) return plan_for_tile(bm, bn, 1);
