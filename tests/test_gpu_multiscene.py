@@ -71,3 +71,26 @@ def test_pipelined_scenes_equal_one_at_a_time(device, prec):
     # an error in the first stage of a later scene reaches the caller
     with pytest.raises(Exception):
         eng.predict_many([seq[0], (seq[1][0].cpu(), seq[1][1], seq[1][2], 0.02)])
+
+
+def test_pipeline_sequence_lengths_and_run_ahead(device):
+    """The host runs the first-stage phases of up to two scenes ahead of the network it is enqueuing and keeps at most
+    eight scenes in flight: sequences of one and two scenes, a generator as input, three network streams and a
+    sequence longer than the run-ahead bound all give the one-at-a-time results."""
+    import bench
+    eng, _, _ = bench.build_engine(device, "bf16x6")
+    seq = []
+    for i, target in enumerate([4000, 12000, 800]):
+        sc = scenes.make_scene(seed=70 + i, target_voxels=target)
+        n = sc["coord"].shape[0]
+        seq.append((torch.from_numpy(sc["coord"]).to(device), torch.from_numpy(sc["feat"]).to(device),
+                    np.array([0, n], dtype=np.int64), 0.02))
+    with torch.no_grad():
+        ref = [eng.predict(*sc)["pred"] for sc in seq]
+        for k in (1, 2, 3):
+            got = eng.predict_many(seq[:k], net_streams=3)
+            assert [torch.equal(g["pred"], r) for g, r in zip(got, ref)] == [True] * k
+        got = eng.predict_many((seq[i % 3] for i in range(7)), net_streams=2)     # a generator
+        assert len(got) == 7 and all(torch.equal(g["pred"], ref[i % 3]) for i, g in enumerate(got))
+        got = eng.predict_many([seq[i % 3] for i in range(26)], net_streams=3)      # beyond the run-ahead bound
+        assert len(got) == 26 and all(torch.equal(g["pred"], ref[i % 3]) for i, g in enumerate(got))
