@@ -167,3 +167,21 @@ def test_module_sparsify_options(device):
     assert np.array_equal(vox2["v2p_map"].cpu().numpy(), spf["v2p_map"])
     with pytest.raises(ValueError):
         net2.sparsify(dict(grid_coord=gc + 1, feat=f, offset=sc["offset"]))
+
+
+def test_deferred_completion_equals_the_blocking_call(device):
+    """voxelize(defer=True) enqueues the same kernels and hands the sizes over through a pinned buffer: several calls
+    may be in flight before the first is finished, in any order of completion, and each yields what the blocking
+    call yields."""
+    scs = [scenes.make_scene(seed=60 + i, target_voxels=t) for i, t in enumerate([3000, 9000, 500])]
+    args = [(torch.from_numpy(s["coord"]).to(device), torch.from_numpy(s["feat"]).to(device),
+             np.array([0, s["coord"].shape[0]], dtype=np.int64), 0.02) for s in scs]
+    ref = [ops.voxelize(*a, return_keys=True) for a in args]
+    fins = [ops.voxelize(*a, return_keys=True, defer=True) for a in args]
+    for i in (2, 0, 1):
+        got = fins[i]()
+        assert got["n_voxels"] == ref[i]["n_voxels"] and got["spatial_shape"] == ref[i]["spatial_shape"]
+        for k in ("voxel_coords", "voxel_feats", "v2p_map", "keys"):
+            assert torch.equal(got[k], ref[i][k]), k
+    with pytest.raises(ValueError):
+        ops.voxelize(*args[0], pooling_method="random", defer=True)
