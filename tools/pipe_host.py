@@ -9,7 +9,7 @@ eng, model, cfg = bench.build_engine(dev, prec)
 sc = scenes.make_scene(seed=0, target_voxels=bench.TARGET_VOXELS)
 n = sc["coord"].shape[0]
 one = (torch.from_numpy(sc["coord"]).to(dev), torch.from_numpy(sc["feat"]).to(dev), np.array([0, n]), 0.02)
-for ns in (2, 3):
+for ns in [int(x) for x in os.environ.get("NS", "2,3").split(",")]:
     eng.predict_many([one] * 4, net_streams=ns)
     torch.cuda.synchronize()
     eng.pipe_log = []
