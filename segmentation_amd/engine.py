@@ -148,6 +148,7 @@ class SpUNetEngine:
         self.dec = [[block(f"dec.{s}.block{i}") for i in range(layers[len(ch) - s - 1])]
                     for s in range(self.num_stages)]
         self.final = conv("final.weight", None, "final.bias")
+        self.final_head = None   # `final` in the format of the fused head where that differs from the backbone's
         self.text = None
         self.n_classes = 0
         self.last_stats = {}
@@ -190,9 +191,16 @@ class SpUNetEngine:
         self.text = self._make_conv(ops.pack_weight(w, self.head_precision), None, None)
         self.n_classes = c
         # one-kernel head (last 1x1 layer + logits + argmax): 2- and 3-term split precisions, supported shapes only
+        # (plain bf16 runs the two-term head on the two-term split of its last block's f32 output, with `final` packed
+        # a second time with two terms: the 768-d features then never travel, and the head is the more accurate one)
         self.text_fused = None
-        if self._terms in (2, 3, 4) and self.fuse_head and ops.head_fused_supported(self.final.w.cin, c):
-            self.text_fused = ops.head_pack_text(emb, cin=self.final.w.cin, terms=self._terms)
+        self._head_terms = 2 if self._terms == 1 else self._terms
+        if self._terms in (1, 2, 3, 4) and self.fuse_head and ops.head_fused_supported(self.final.w.cin, c):
+            self.text_fused = ops.head_pack_text(emb, cin=self.final.w.cin, terms=self._head_terms)
+            if self._terms == 1 and self.final_head is None:
+                w2 = ops.pack_weight(self._sd["final.weight"], "bf16x3", self.device)
+                b2 = self._sd["final.bias"].float().contiguous() if "final.bias" in self._sd else None
+                self.final_head = self._make_conv(w2, None, b2)
         # folded head: logits = x96 . (E Wf)^T + E bf   (no nonlinearity between `final` and the head)
         wf = self._sd["final.weight"].reshape(self.final.cout, -1).double().to(self.device)
         wfold = torch.zeros((cpad, 1, wf.shape[1]), dtype=torch.float32, device=self.device)
@@ -282,7 +290,7 @@ class SpUNetEngine:
         return self._conv(blk["conv2"], t, sched, n, residual=res, relu=True,
                           need_f32=last_needs_f32 or self._terms == 0)
 
-    def backbone(self, voxel_feats, levels, keep=None):
+    def backbone(self, voxel_feats, levels, keep=None, last_f32=False):
         """SpUNetBase.forward after sparsify (v1m3:388-407).  Returns the activation pair of the last decoder
         block ([N0, channels[-1]])."""
         ns = self.num_stages
@@ -311,7 +319,7 @@ class SpUNetEngine:
                 # the network's last block feeds `final` / the head, which read the split copy only
                 last = s == 0 and i == len(self.dec[s]) - 1 and keep is None
                 x = self._block(blk, x, levels[s].subm, levels[s].n, x2=skip if i == 0 else None,
-                                last_needs_f32=not last)
+                                last_needs_f32=last_f32 or not last)
             if keep is not None:
                 keep[f"dec.{s}"] = x[0]
         return x
@@ -527,9 +535,15 @@ class SpUNetEngine:
         self.last_stats = dict(n_points=n_points, n_voxels=[levels[l].n for l in range(len(levels))])
         if self.text_fused is not None and not fold_head and not return_features:
             # `final`, the logits and the argmax in one kernel: the CLIP features stay on chip
-            x = self.backbone(vox["voxel_feats"], levels)
-            vlabel, logits = ops.head_fused(x[1], self.final.w, self.text_fused, scale=self.final.scale,
-                                            shift=self.final.shift, want_logits=return_logits)
+            fin = self.final_head if self.final_head is not None else self.final
+            if self._head_terms != self._terms:
+                # the head's operand format differs from the backbone's: split the f32 copy of the last block's output
+                x = self.backbone(vox["voxel_feats"], levels, last_f32=True)
+                xs = ops.split_f32(x[0], self._head_terms)
+            else:
+                xs = self.backbone(vox["voxel_feats"], levels)[1]
+            vlabel, logits = ops.head_fused(xs, fin.w, self.text_fused, scale=fin.scale, shift=fin.shift,
+                                            want_logits=return_logits)
         elif fold_head:
             x = self.backbone(vox["voxel_feats"], levels)
             t = self.text_folded

@@ -20,9 +20,12 @@ with torch.no_grad():
         sync(); t0 = time.perf_counter()
         vox = ops.voxelize(coord, feat, off, 0.02, pad=128); sync(); t1 = time.perf_counter()
         levels = eng.build_levels(vox["voxel_coords"], vox["spatial_shape"], vox["batch_size"]); sync(); t2 = time.perf_counter()
-        x = eng.backbone(vox["voxel_feats"], levels); sync(); t3 = time.perf_counter()
+        other = eng.text_fused is not None and eng._head_terms != eng._terms   # the head's format is not the backbone's
+        x = eng.backbone(vox["voxel_feats"], levels, last_f32=other); sync(); t3 = time.perf_counter()
         if eng.text_fused is not None:   # last layer + logits + argmax in one kernel
-            vl, _ = ops.head_fused(x[1], eng.final.w, eng.text_fused, scale=eng.final.scale, shift=eng.final.shift)
+            fin = eng.final_head if eng.final_head is not None else eng.final
+            xs = ops.split_f32(x[0], eng._head_terms) if other else x[1]
+            vl, _ = ops.head_fused(xs, fin.w, eng.text_fused, scale=fin.scale, shift=fin.shift)
         else:
             pair = eng._conv(eng.final, x, None, levels[0].n, need_f32=True, need_sf=eng._terms != 0)
             src = pair[1] if eng._terms else pair[0]
