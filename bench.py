@@ -44,7 +44,7 @@ TARGET_VOXELS = 290_000        # scene-generator target; lands at ~273 k occupie
 CFG3_SCENES = 64
 
 
-def build_engine(device, precision=HEADLINE):
+def build_engine(device, precision=HEADLINE, label_head=None):
     import torch
     from segmentation_amd import spunet
     from segmentation_amd.engine import SpUNetEngine
@@ -54,7 +54,7 @@ def build_engine(device, precision=HEADLINE):
     model = spunet.PPT(spunet.SpUNet(**{k: cfg[k] for k in ("in_channels", "out_channels", "base_channels",
                                                              "context_channels", "channels", "layers",
                                                              "conditions")}), cfg["conditions"], 256).eval()
-    eng = SpUNetEngine(model, cfg, "ScanNet", device, precision=precision)
+    eng = SpUNetEngine(model, cfg, "ScanNet", device, precision=precision, label_head=label_head)
     eng.set_text_embeddings(torch.from_numpy(scenes.text_embeddings(N_CLASSES, cfg["out_channels"], seed=1)))
     return eng, model, cfg
 

@@ -86,10 +86,17 @@ class _Level:
 
 class SpUNetEngine:
     def __init__(self, model_or_state: object, cfg: Dict, condition: str = "ScanNet", device="cuda",
-                 precision: str = "f32"):
+                 precision: str = "f32", label_head: Optional[str] = None):
         """model_or_state: a PPT module (segmentation_amd.spunet.PPT or the reference's) or its state_dict
-        ('backbone.*' + 'embedding_table.weight').  cfg: channels / layers / conditions of the backbone."""
+        ('backbone.*' + 'embedding_table.weight').  cfg: channels / layers / conditions of the backbone.
+        label_head: None, or "bf16x3" / "f16x3" / "bf16x6": the precision of the fused head (last layer + text logits +
+        argmax) when a call asks for labels only -- the logits then feed nothing but the argmax, and two-term products
+        give the same labels as the f32-level ones at half the cost.  Features and logits, when asked for, are always
+        computed at the engine's precision."""
         self.device = torch.device(device)
+        if label_head is not None and label_head not in ("bf16x3", "f16x3", "bf16x6"):
+            raise ValueError("label_head must be None, 'bf16x3', 'f16x3' or 'bf16x6'")
+        self.label_head = label_head
         with torch.cuda.device(self.device):
             self._init(model_or_state, cfg, condition, precision)
 
@@ -194,11 +201,11 @@ class SpUNetEngine:
         # (plain bf16 runs the two-term head on the two-term split of its last block's f32 output, with `final` packed
         # a second time with two terms: the 768-d features then never travel, and the head is the more accurate one)
         self.text_fused = None
-        self._head_terms = 2 if self._terms == 1 else self._terms
-        if self._terms in (1, 2, 3, 4) and self.fuse_head and ops.head_fused_supported(self.final.w.cin, c):
+        self._head_terms = ops.TERMS[self.label_head] if self.label_head else (2 if self._terms == 1 else self._terms)
+        if self._head_terms in (2, 3, 4) and self.fuse_head and ops.head_fused_supported(self.final.w.cin, c):
             self.text_fused = ops.head_pack_text(emb, cin=self.final.w.cin, terms=self._head_terms)
-            if self._terms == 1 and self.final_head is None:
-                w2 = ops.pack_weight(self._sd["final.weight"], "bf16x3", self.device)
+            if self._head_terms != self._terms and self.final_head is None:
+                w2 = ops.pack_weight(self._sd["final.weight"], ops.PRECISION_OF_TERMS[self._head_terms], self.device)
                 b2 = self._sd["final.bias"].float().contiguous() if "final.bias" in self._sd else None
                 self.final_head = self._make_conv(w2, None, b2)
         # folded head: logits = x96 . (E Wf)^T + E bf   (no nonlinearity between `final` and the head)
@@ -533,7 +540,10 @@ class SpUNetEngine:
         else:
             vox, levels, n_points = maps
         self.last_stats = dict(n_points=n_points, n_voxels=[levels[l].n for l in range(len(levels))])
-        if self.text_fused is not None and not fold_head and not return_features:
+        # the fused head serves a call unless it asks for the features, or for logits while the head's precision is a
+        # labels-only choice (label_head)
+        if self.text_fused is not None and not fold_head and not return_features and \
+                not (return_logits and self.label_head is not None):
             # `final`, the logits and the argmax in one kernel: the CLIP features stay on chip
             fin = self.final_head if self.final_head is not None else self.final
             if self._head_terms != self._terms:

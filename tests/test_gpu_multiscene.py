@@ -94,3 +94,30 @@ def test_pipeline_sequence_lengths_and_run_ahead(device):
         assert len(got) == 7 and all(torch.equal(g["pred"], ref[i % 3]) for i, g in enumerate(got))
         got = eng.predict_many([seq[i % 3] for i in range(26)], net_streams=3)      # beyond the run-ahead bound
         assert len(got) == 26 and all(torch.equal(g["pred"], ref[i % 3]) for i, g in enumerate(got))
+
+
+@pytest.mark.parametrize("prec", ["bf16x6", "f32"])
+def test_labels_only_head_precision(device, prec):
+    """label_head="bf16x3": calls that ask for labels only take them from the two-term fused head (>= 99.9 % agreement
+    with the engine's own precision, the bar of the whole path); logits and features are still computed at the
+    engine's precision."""
+    import bench
+    eng, _, _ = bench.build_engine(device, prec)
+    fast, _, _ = bench.build_engine(device, prec, label_head="bf16x3")
+    sc = scenes.make_scene(seed=81, target_voxels=20000)
+    n = sc["coord"].shape[0]
+    a = (torch.from_numpy(sc["coord"]).to(device), torch.from_numpy(sc["feat"]).to(device),
+         np.array([0, n], dtype=np.int64), 0.02)
+    with torch.no_grad():
+        ref = eng.predict(*a, return_logits=True)
+        got = fast.predict(*a)
+        assert (got["pred"] == ref["pred"]).float().mean().item() >= 0.999
+        assert torch.equal(got["v2p_map"], ref["v2p_map"])
+        full = fast.predict(*a, return_logits=True)
+        # (same precision, but the engine's own fused head and the unfused chain round in different orders)
+        assert torch.allclose(full["voxel_logits"], ref["voxel_logits"], rtol=1e-4, atol=1e-6)
+        assert (full["pred"] == ref["pred"]).float().mean().item() >= 0.999
+        f1, f2 = fast.predict(*a, return_features=True), eng.predict(*a, return_features=True)
+        assert torch.equal(f1["voxel_feat"], f2["voxel_feat"])
+        many = fast.predict_many([a] * 3, net_streams=2)
+        assert all(torch.equal(m["pred"], got["pred"]) for m in many)
