@@ -389,7 +389,10 @@ struct UnitIt {  // position in the unit sequence of a tile: kernel offset k (lo
 
 // AF: the activations are plain f32 rows (s0 / s1 = [rows][C] f32, no zero row: missing neighbours read zbuf) and
 // the terms are formed in registers after the fragment read (T == 2 or 3); the weights are split as always.
-template <int WM, int WN, int NT, int T, int NBUF, bool AF>
+// GMAP: the kernel map stays in global memory; LDS holds the rows of two kernel offsets only (the one whose requests
+// are being issued and the next one, fetched by an LDS-DMA of its own one offset ahead), which leaves room for a third
+// workgroup per CU beside the 128-row x 96-column output staging.
+template <int WM, int WN, int NT, int T, int NBUF, bool AF, bool GMAP>
 __device__ __forceinline__ void conv_igemm_dma_body(const ConvArgs& a) {
   using G = DmaGeom<T>;                                                        // weight image
   // activation image: 16 f32 channels are 64 bytes (T = 3); 32 f32 channels are the 128 bytes of the two-term unit
@@ -411,8 +414,8 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvArgs& a) {
   static_assert(NBUF >= 2 && NBUF <= 4, "ring depth");
   extern __shared__ __align__(16) char ldsb[];
   constexpr int RING = NBUF * BUF > BM * BN * 4 ? NBUF * BUF : BM * BN * 4;  // the output tile is staged here too
-  int* idx_s = reinterpret_cast<int*>(ldsb + RING);  // [kvol][BM]
-  int* orow_s = idx_s + a.kvol * BM;
+  int* idx_s = reinterpret_cast<int*>(ldsb + RING);  // [kvol][BM]; GMAP: [2][BM]
+  int* orow_s = idx_s + (GMAP ? 2 : a.kvol) * BM;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -430,6 +433,7 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvArgs& a) {
   // request itself cost its wave more).  A missing neighbour gets an offset beyond the buffer's size: the hardware
   // then writes zeros to LDS without a memory request.  Operands are limited to kDmaBufferBytes (checked by the host).
   constexpr bool BUFA = !AF && UPS == 1;
+  static_assert(!GMAP || (BUFA && BM == 128 && NBUF == 2), "kernel map in global memory: 128-row tiles of the buffer-addressed path");
   constexpr int kRsrcWord3 = 0x00020000;  // raw buffer, 32-bit elements
   const __amdgpu_buffer_rsrc_t rs0 =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(a.s0), (short)0, (int)kDmaBufferBytes, kRsrcWord3);
@@ -446,10 +450,16 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvArgs& a) {
     const int64_t t = tile_base + r;
     orow_s[r] = a.out_row ? a.out_row[t] : (t < a.n ? (int)t : -1);
   }
-  for (int e = tid; e < a.kvol * BM; e += NTHR) {
-    const int k = e / BM, r = e % BM;
-    const int64_t t = tile_base + r;
-    idx_s[e] = a.nbr ? a.nbr[(int64_t)k * a.npad + t] : (t < a.n ? (int)t : -1);
+  if constexpr (GMAP) {  // the rows of the first two active offsets
+    const uint32_t rem1 = bmask & (bmask - 1);
+    if (tid < BM && bmask) idx_s[tid] = a.nbr[(int64_t)__builtin_ctz(bmask) * a.npad + tile_base + tid];
+    if (tid >= NTHR - BM && rem1) idx_s[tid - (NTHR - 2 * BM)] = a.nbr[(int64_t)__builtin_ctz(rem1) * a.npad + tile_base + tid - (NTHR - BM)];
+  } else {
+    for (int e = tid; e < a.kvol * BM; e += NTHR) {
+      const int k = e / BM, r = e % BM;
+      const int64_t t = tile_base + r;
+      idx_s[e] = a.nbr ? a.nbr[(int64_t)k * a.npad + t] : (t < a.n ? (int)t : -1);
+    }
   }
   __syncthreads();
 
@@ -505,11 +515,12 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvArgs& a) {
   UnitIt it{bmask, bmask ? __builtin_ctz(bmask) : 0, 0};
   int issued = 0;  // units requested so far
   int a_id[A_V];
+  int it_par = 0;  // GMAP: which of the two LDS rows holds the kernel map of it.k
   auto load_ids = [&]() {
     UnitIt n1 = it;
     if (UPS == 2) step(n1);
 #pragma unroll
-    for (int v = 0; v < A_V; ++v) a_id[v] = idx_s[(a_u[v] ? n1.k : it.k) * BM + a_r[v]];
+    for (int v = 0; v < A_V; ++v) a_id[v] = idx_s[(GMAP ? it_par : a_u[v] ? n1.k : it.k) * BM + a_r[v]];
     if constexpr (BUFA) {
 #pragma unroll
       for (int v = 0; v < A_V; ++v) {
@@ -555,7 +566,18 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvArgs& a) {
           if ((W_EXACT && NO_DEAD) || w_on[v])
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr_t)(buf + A_BYTES + (v * NTHR + wave * 64) * 16), 16,
                                                      w_o[v], soff_w, 0, 0);
-      if (issued < nunit && it.k != k_before) load_ids();
+      if (issued < nunit && it.k != k_before) {
+        if constexpr (GMAP) {
+          it_par ^= 1;
+          // the row the previous offset used is free (every wave read it before this stage's barrier): it receives
+          // the offset after this one, which lands and is published long before its first request is formed
+          const uint32_t rem2 = it.rem & (it.rem - 1);
+          if (rem2 && wave < BM / 64)
+            __builtin_amdgcn_global_load_lds(a.nbr + ((int64_t)__builtin_ctz(rem2) * a.npad + tile_base + wave * 64 + lane),
+                                             (lds_ptr_t)(idx_s + (it_par ^ 1) * BM + wave * 64), 4, 0, 0);
+        }
+        load_ids();
+      }
       return;
     }
     const char* src[UPS];
@@ -829,9 +851,9 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvArgs& a) {
   }
 }
 
-template <int WM, int WN, int NT, int T, int NBUF, bool AF = false>
+template <int WM, int WN, int NT, int T, int NBUF, bool AF = false, bool GMAP = false>
 __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_dma_kernel(ConvArgs a) {
-  conv_igemm_dma_body<WM, WN, NT, T, NBUF, AF>(a);
+  conv_igemm_dma_body<WM, WN, NT, T, NBUF, AF, GMAP>(a);
 }
 
 // f32 [n][c] -> sf32 [n + 1][c/32][terms][32] bf16 (row n zero).  One thread per element.
@@ -1031,16 +1053,16 @@ static int launch_split(const ConvArgs& a, int nz, hipStream_t stream) {
   return M3D_OK;
 }
 
-template <int WM, int WN, int NT, int T, int NBUF, bool AF = false>
+template <int WM, int WN, int NT, int T, int NBUF, bool AF = false, bool GMAP = false>
 static int launch_dma_n(const ConvArgs& a, int nz, hipStream_t stream) {
   constexpr int BM = 32 * WM, BN = 32 * NT * WN, NTHR = 64 * WM * WN;
   constexpr int A_ROWB = AF && T == 3 ? DmaGeomF32::ROWB : DmaGeom<T>::ROWB;
   constexpr size_t ring = (size_t)NBUF * (BM * A_ROWB + BN * DmaGeom<T>::ROWB), tile = (size_t)BM * BN * sizeof(float);
-  const size_t lds = (ring > tile ? ring : tile) + (size_t)(a.kvol + 1) * BM * sizeof(int);
+  const size_t lds = (ring > tile ? ring : tile) + (size_t)((GMAP ? 2 : a.kvol) + 1) * BM * sizeof(int);
   static LdsGrant grant;
-  if (int rc = grant.ensure(reinterpret_cast<const void*>(&conv_igemm_dma_kernel<WM, WN, NT, T, NBUF, AF>), lds)) return rc;
+  if (int rc = grant.ensure(reinterpret_cast<const void*>(&conv_igemm_dma_kernel<WM, WN, NT, T, NBUF, AF, GMAP>), lds)) return rc;
   dim3 grid((unsigned)(a.npad / BM), (unsigned)(a.cout / BN), (unsigned)nz);
-  hipLaunchKernelGGL((conv_igemm_dma_kernel<WM, WN, NT, T, NBUF, AF>), grid, dim3(NTHR), lds, stream, a);
+  hipLaunchKernelGGL((conv_igemm_dma_kernel<WM, WN, NT, T, NBUF, AF, GMAP>), grid, dim3(NTHR), lds, stream, a);
   M3D_LAUNCH_CHECK();
   return M3D_OK;
 }
@@ -1093,6 +1115,12 @@ static int launch_dma(const ConvArgs& a, int nz, hipStream_t stream) {
   while (nbuf > 2 && nbuf * per_buf + idx > 160 * 1024) --nbuf;
   if (nbuf >= 4) return launch_dma_n<WM, WN, NT, T, 4>(a, nz, stream);
   if (nbuf == 3) return launch_dma_n<WM, WN, NT, T, 3>(a, nz, stream);
+  if constexpr (T == 3 && BM == 128 && BN == 96) {
+    // Largest level only: with the kernel map out of LDS three workgroups fit a CU.  Launches of fewer tiles keep
+    // two (a third workgroup per CU leaves part of the chip without work in their last round).
+    static const int64_t gmap_tiles = getenv("M3D_GMAP_TILES") ? atoll(getenv("M3D_GMAP_TILES")) : 1024;
+    if (a.nbr && nz == 1 && a.npad / BM >= gmap_tiles) return launch_dma_n<WM, WN, NT, T, 2, false, true>(a, nz, stream);
+  }
   return launch_dma_n<WM, WN, NT, T, 2>(a, nz, stream);
 }
 

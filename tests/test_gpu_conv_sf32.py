@@ -1,6 +1,10 @@
 """The LDS-DMA convolution on split-format (sf32) activations (m3d_conv_fwd_sf32, m3d_split_f32) against the
 CPU oracle.  Tolerances, per-row relative L2 over one layer: terms=3 (bf16x6) 1e-5, terms=2 (bf16x3) 6e-5,
 terms=1 (plain bf16 operands, f32 accumulation) 1e-2, format 4 (f16x3: operands as f16 pairs exact to 2^-22) 1e-5."""
+import os
+import subprocess
+import sys
+
 import numpy as np
 import pytest
 import torch
@@ -183,6 +187,28 @@ def test_f32_rows_with_split_products_equal_the_presplit_path(device, target, te
     x96 = torch.randn(n, 96, generator=g).to(device)
     assert torch.equal(ops.conv_fwd(x96, w1, None, n), ops.conv_fwd(ops.split_f32(x96, terms), w1, None, n))
 
+
+
+def test_three_workgroups_per_cu_variant(device, tmp_path):
+    """Launches of 1024 and more 128-row x 96-column tiles at three terms keep the kernel map in global memory (three
+    workgroups per CU).  Same bits as the two-workgroup kernel (run in a child process with the variant switched off
+    through M3D_GMAP_TILES), and both within the three-term tolerance of the oracle."""
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import _conv_large_child as child
+    r = child.run(device)
+    assert r["n"] >= 1024 * 128
+    ref1 = oracle.subm_conv(r["xa"], r["w1"], r["pair"])
+    assert _rel(r["out1"], ref1) < TOL[3]
+    ref2 = torch.relu(oracle.subm_conv(torch.cat((r["xa"], r["xb"]), 1), r["w2"], r["pair"]) * r["scale"] + r["shift"] + r["res"])
+    assert _rel(r["out2"], ref2) < TOL[3]
+    path = str(tmp_path / "off.npz")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, M3D_GMAP_TILES="1000000000", PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    subprocess.run([sys.executable, child.__file__, path], check=True, env=env, timeout=300)
+    off = np.load(path)
+    assert np.array_equal(off["out1"], r["out1"].numpy())
+    assert np.array_equal(off["out2"], r["out2"].numpy())
+    assert np.array_equal(off["osp"], r["osp"].numpy())
 
 
 def test_f16_status_reports_values_beyond_the_f16_range(device):
