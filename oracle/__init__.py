@@ -15,6 +15,10 @@ Pinning status
   classes (tests/golden/reference_preprocess.npz, produced by tests/golden/make_golden_preprocess.py).  The
   Stray Scanner converter (convert_stray.py) needs open3d, absent here: its three arithmetic lines are restated
   and checked by known answers only.
+* the open-vocabulary head (oracle/head.py) and the caption loss of the training step (oracle/caption_loss.py):
+  pinned against outputs of the reference's own CLIPAlignmentEval.predict (on the features of the reference's own
+  forward pass) and CaptionLoss.loss / extract_text_features with their gradients (tests/golden/reference_loss.npz,
+  produced by tests/golden/make_golden_loss.py from /root/reference).
 * sparse-conv kernel maps and convolution arithmetic: the reference delegates these to the
   un-vendored third-party wheel ``spconv-cu120`` (version unpinned in
   /root/reference/mosaic3d/requirements.txt:41), which is not installed anywhere and has no
@@ -29,4 +33,5 @@ from .sparse_conv import (subm_conv, strided_conv, inverse_conv, conv1x1, dense_
                           dense_equivalent_strided)
 from .head import head_logits, head_predict
 from . import preprocess
+from . import caption_loss
 from .spunet import spunet_forward, fold_pdnorm, make_spunet_params, SPUNET34C

@@ -558,7 +558,8 @@ class SpUNetEngine:
             x = self.backbone(vox["voxel_feats"], levels)
             t = self.text_folded
             src = x[1] if self._terms else x[0]
-            logits = ops.conv_fwd(src, t.w, None, levels[0].n, shift=t.shift, flop_cout=self.n_classes)
+            # (a weight packed with a power-of-two factor carries the inverse in t.scale: precision "f16x3")
+            logits = ops.conv_fwd(src, t.w, None, levels[0].n, scale=t.scale, shift=t.shift, flop_cout=self.n_classes)
         else:
             # the head consumes the split features directly; the f32 copy is only written when asked for
             x = self.backbone(vox["voxel_feats"], levels)
@@ -566,7 +567,7 @@ class SpUNetEngine:
                               need_sf=self._terms != 0)
             src = pair[1] if self._terms else pair[0]
             vfeat = pair[0]
-            logits = ops.conv_fwd(src, self.text.w, None, levels[0].n, flop_cout=self.n_classes)
+            logits = ops.conv_fwd(src, self.text.w, None, levels[0].n, scale=self.text.scale, flop_cout=self.n_classes)
         if vlabel is None:
             vlabel = ops.argmax_rows(logits, self.n_classes)
         plabel = ops.gather_labels(vlabel, vox["v2p_map"])

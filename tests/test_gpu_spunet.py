@@ -107,6 +107,15 @@ def test_f16_pairs_match_the_oracle_at_f32_level(device):
     assert out["precision"] == "f16x3"
     ref_pred = oracle.head_predict(ref, sp["v2p_map"], emb)
     assert (out["pred"].cpu() == ref_pred).float().mean().item() >= 0.999
+    # every way to the logits carries the power of two the weights were packed with: the fused head, `final` folded
+    # into the text matrix, and the unfused text product behind the written-out features
+    ref_logits = oracle.head_logits(ref, np.arange(ref.shape[0]), emb)
+    for kw in (dict(return_logits=True), dict(fold_head=True, return_logits=True),
+               dict(return_features=True, return_logits=True)):
+        o = eng.predict(coord, feat, b["offset"], 0.02, **kw)
+        assert _rel_rows(o["voxel_logits"], ref_logits) < 1e-4, kw
+        assert (o["pred"].cpu() == ref_pred).float().mean().item() >= 0.999, kw
+    assert eng.f16_range_exceeded(clear=True) is False
 
 
 def test_module_path_matches_oracle(device, case):

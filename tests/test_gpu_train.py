@@ -9,6 +9,7 @@ import pytest
 import torch
 
 import oracle
+from oracle import caption_loss as oracle_loss
 from segmentation_amd import ops, scenes, sparse, spunet, train
 
 pytestmark = pytest.mark.gpu
@@ -151,7 +152,7 @@ def _caption_batch(rng, n_pts, n_caps, d, device):
                 num_points_per_caption=npc)
 
 
-def test_caption_loss_matches_a_direct_restatement(device):
+def test_caption_loss_matches_the_oracle(device):
     rng = np.random.default_rng(0)
     n, d = 4000, 64
     feats = torch.from_numpy(rng.normal(size=(n, d)).astype(np.float32))
@@ -160,13 +161,11 @@ def test_caption_loss_matches_a_direct_restatement(device):
     fg = feats.to(device).requires_grad_(True)
     loss = train.caption_loss(fg, text, seg, cd["point_indices"], cd["caption_offsets"], cd["num_points_per_caption"])
     loss.backward()
-    # restatement of caption_loss.py:212-235 in float64 on the CPU, caption by caption
+    # the CPU oracle in float64 (pinned to the reference's own CaptionLoss.loss by tests/golden/reference_loss.npz)
     fr = feats.double().requires_grad_(True)
-    scores = torch.log_softmax(torch.nn.functional.normalize(fr, dim=-1) @ text.cpu().double().T, dim=-1)
-    co, pi = cd["caption_offsets"], cd["point_indices"].cpu()
-    per = torch.stack([-scores[pi[co[s]:co[s + 1]]].mean(0)[seg[s].item()] for s in range(len(co) - 1)])
-    w = cd["num_points_per_caption"].double()
-    ref = (per * w).sum() / w.sum()
+    emb64 = [[e.cpu().double() for e in cd["embedding"][0]]]
+    ref = oracle_loss.caption_loss(fr, emb64, cd["point_indices"].cpu(), cd["caption_offsets"],
+                                   cd["num_points_per_caption"])
     ref.backward()
     assert abs(loss.item() - ref.item()) < 1e-5 * abs(ref.item())
     assert _rel(fg.grad, fr.grad) < 1e-4
@@ -226,9 +225,11 @@ def test_whole_training_step_matches_cpu_oracle(device, monkeypatch, fold_head):
     monkeypatch.setenv("M3D_FOLD_MODULATIONS", "0")
     with _CpuConvs():
         out = ref(bc)
-        text, seg, _ = train.unique_text_features(cdc["embedding"])
-        loss_ref = train.caption_loss(out["sparse_conv_feat"].features[out["v2p_map"]], text, seg, cdc["point_indices"],
-                                      cdc["caption_offsets"], cdc["num_points_per_caption"])
+        # the loss by the CPU oracle (oracle/caption_loss.py, pinned to the reference's CaptionLoss.loss by
+        # tests/golden/reference_loss.npz), not by the product's own function
+        loss_ref = oracle_loss.training_loss(out["sparse_conv_feat"].features, out["v2p_map"], cdc["embedding"],
+                                             cdc["point_indices"], cdc["caption_offsets"],
+                                             cdc["num_points_per_caption"])
         loss_ref.backward()
     assert abs(loss.item() - loss_ref.item()) < 1e-4 * abs(loss_ref.item())
     checked = 0

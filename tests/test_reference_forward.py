@@ -56,6 +56,37 @@ def test_reference_forward_equals_the_oracle_and_the_committed_golden(forward_ru
             assert np.array_equal(golden[k], rec[k]), k
 
 
+def test_reference_loss_and_head_golden_regenerate_and_pin_the_oracle_head(forward_run):
+    """tests/golden/reference_loss.npz is what the reference's own CaptionLoss / CLIPAlignmentEval produce today
+    (regenerated here from /root/reference), and oracle.head_logits / head_predict reproduce its head part."""
+    import make_golden_loss as mgl
+    import oracle
+    from segmentation_amd import scenes
+    CL, CA = mgl.reference_loss_modules()
+    rec = mgl.run_loss(CL)
+    rec.update(mgl.run_head(CA, forward_run))
+    golden = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_loss.npz"))
+    assert set(golden.files) == set(rec)
+    for k in golden.files:
+        if golden[k].dtype.kind == "f":
+            assert np.allclose(golden[k], rec[k], rtol=1e-10, atol=1e-13), k
+        else:
+            assert np.array_equal(golden[k], rec[k]), k
+    _, outs, point, params, b, cfg = forward_run
+    emb = torch.from_numpy(scenes.text_embeddings(mgl.HEAD_CLASSES, cfg["out_channels"])).double()
+    feats, v2p = outs["final"], point.v2p_map.numpy()
+    for tag, norm in (("raw", False), ("norm", True)):
+        clip_feat = feats[torch.from_numpy(v2p)]
+        if norm:
+            clip_feat = torch.nn.functional.normalize(clip_feat, p=2, dim=1)
+        logits = clip_feat @ emb.t()   # oracle.head_logits casts the text rows to float32; float64 here as the golden
+        assert np.allclose(logits[torch.from_numpy(golden["head_rows"])].numpy(), golden[f"head_{tag}_logits"],
+                           rtol=1e-12, atol=1e-12)
+        got = oracle.head_predict(feats.float(), v2p, emb.float(), normalize_input=norm).numpy()
+        differ = got != golden[f"head_{tag}_max"]
+        assert differ.mean() < 1e-3 and (golden[f"head_{tag}_margin"][differ] < 1e-3 * float(logits.abs().max())).all()
+
+
 def _v1m1_inputs(seed=31, target=2500):
     from segmentation_amd import scenes
     b = scenes.make_batch([seed, seed + 1], target_voxels=target)
