@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include <atomic>
 
 #include "../../include/m3d.h"
 
@@ -34,22 +35,23 @@ int f16_status_ptr(int** out);  // conv.hip: device address of the f16 status wo
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-device property of a kernel: one of these per kernel
 // instantiation (a function-local static) remembers, per device, the largest size already granted.  Racing first
-// calls from two threads both set the attribute, which is harmless.
+// calls from two threads both set the attribute (harmless); the remembered size is an atomic so that the race is
+// only that.
 struct LdsGrant {
-  size_t have[64] = {};
+  std::atomic<size_t> have[64] = {};
   int ensure(const void* fn, size_t lds) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) {
       set_error("hipGetDevice failed or device index out of range");
       return M3D_EHIP;
     }
-    if (lds > have[dev]) {
+    if (lds > have[dev].load(std::memory_order_relaxed)) {
       hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) {
         set_error("hipFuncSetAttribute(%zu bytes of LDS) -> %s", lds, hipGetErrorString(e));
         return M3D_EHIP;
       }
-      have[dev] = lds;
+      have[dev].store(lds, std::memory_order_relaxed);
     }
     return M3D_OK;
   }

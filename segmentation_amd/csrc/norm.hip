@@ -346,6 +346,9 @@ extern "C" size_t m3d_bn_stats_static_max_bytes(void) { return kStaticScratchByt
 
 extern "C" int m3d_bn_stats_static(const float* d_x, int64_t n, int c, float* d_mean, float* d_var, void* stream) {
   const char* who = "m3d_bn_stats_static";
+  M3D_CHECK_ARG(n > 0 && d_x && d_mean && d_var, "%s: null pointer or no rows", who);
+  M3D_CHECK_ARG(c >= 4 && c % 4 == 0 && c <= 4 * kNormThreads, "%s: channel count %d must be a multiple of 4, at most %d",
+                who, c, 4 * kNormThreads);
   const size_t need = m3d_bn_workspace_bytes(n, c);
   if (need > kStaticScratchBytes) {
     set_error("%s: %lld rows x %d channels need %zu bytes of partial sums, the static scratch holds %zu "

@@ -440,6 +440,9 @@ class SpUNetEngine:
                 __slots__ = ("scene", "n_points", "phase", "fin", "vox", "levels", "ready")
 
             pending = {}   # scene number -> _Scene
+            # a list exists before the call (the wait above covers it); anything else may build each scene when it is
+            # asked for, on the caller's stream, behind the networks already enqueued there
+            lazy = not isinstance(scenes, (list, tuple))
             it = iter(scenes)
             fetched = [0]
 
@@ -449,6 +452,14 @@ class SpUNetEngine:
                     sc = next(it, None)
                     if sc is None:
                         return False
+                    if lazy:
+                        side.wait_stream(main)   # the scene's tensors are ready where the caller's stream stands now
+                    for t in sc[:3]:
+                        # the voxelizer reads the inputs on the side stream: their memory must not be handed out again
+                        # (to a network on the caller's stream, say) before it has finished, even if the caller and
+                        # this function drop them right away
+                        if torch.is_tensor(t) and t.is_cuda:
+                            t.record_stream(side)
                     st = _Scene()
                     st.scene, st.n_points, st.phase, st.fin, st.vox, st.levels, st.ready = sc, 0, 0, None, None, None, None
                     pending[fetched[0]] = st

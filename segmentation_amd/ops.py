@@ -3,6 +3,8 @@
 PyTorch supplies device memory, the current HIP stream and nothing else; every operator below
 runs a hand-written gfx950 kernel from libm3d_hip.so."""
 import ctypes
+import os
+import threading
 from dataclasses import dataclass
 from typing import Optional, Sequence
 
@@ -21,10 +23,31 @@ _workspaces = {}
 PROFILE = None
 
 
+_OWNER_THREAD = {}   # device index -> ident of the first host thread that launched on it
+_ALLOW_THREADS = os.environ.get("M3D_ALLOW_THREADS", "0") == "1"
+
+
+def _check_thread(dev: int):
+    """One host thread per GPU drives the operators: workspaces are shared per (device, stream), read-back buffers
+    and the allocator's stream bookkeeping (record_stream of map tensors in SpUNetEngine.predict_many) assume that
+    the thread that enqueues a producer also enqueues its consumers.  The first thread to launch on a device owns
+    it; a launch from another thread raises unless M3D_ALLOW_THREADS=1 (the caller then orders streams, workspaces
+    and tensor lifetimes across its threads itself).  The autograd engine's backward thread is exempt: it runs
+    while the owner waits in backward(), on the stream the forward ran on."""
+    me = threading.get_ident()
+    owner = _OWNER_THREAD.setdefault(dev, me)
+    if owner != me and not _ALLOW_THREADS and torch._C._current_graph_task_id() == -1:
+        raise RuntimeError(f"segmentation_amd operators on cuda:{dev} are driven by one host thread (the first that "
+                           "launched there); this call comes from another thread.  Use one process per GPU and one "
+                           "thread per process, or set M3D_ALLOW_THREADS=1 and synchronise the threads yourself")
+
+
 def _raw_stream() -> int:
     """Handle of the current stream of the current device.  (torch.cuda.current_stream() builds a Stream object and
     re-validates the device on every call: a quarter of the host time of a scene before this replaced it.)"""
-    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
+    dev = torch._C._cuda_getDevice()
+    _check_thread(dev)
+    return torch._C._cuda_getCurrentRawStream(dev)
 
 
 def _stream():

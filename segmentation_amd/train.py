@@ -192,6 +192,18 @@ def flatten_caption_indices(batched_indices: Sequence[Sequence[torch.Tensor]], b
     return torch.cat(idx), offsets, counts
 
 
+def mix3d_offset(offset):
+    """The Mix3D step of the reference, literally: cat(offset[1:-1:2], offset[-1:]) (language_module.py:212-214 in the
+    training step, collate.py:154-157 in the collate function).  On offsets WITHOUT a leading zero, [a, b, c, d]
+    becomes [b, d]: neighbouring samples merged in pairs.  The reference applies the line to the offsets its own
+    collate builds, which carry a leading zero (collate.py:96-102): [0, a, b, c, d] becomes [a, c, d], i.e. the samples
+    [0, a), [a, c), [c, d) once offset2bincount has put the zero back (misc.py:8-13), and [0, a, b] becomes [a, b]
+    (nothing merged).  This function keeps that behaviour for both conventions, so a batch gives the result the
+    reference gives for it."""
+    offset = torch.as_tensor(offset)
+    return torch.cat([offset[1:-1:2], offset[-1:]], dim=0)
+
+
 class GradientReducer:
     """Data-parallel gradient averaging (configs/trainer/ddp.yaml:4-10: one process per GPU, local batch-norm
     statistics), bucketed and overlapped with the backward pass.
@@ -397,8 +409,7 @@ class TrainStep:
         self.model.train()
         self.opt.zero_grad(set_to_none=True)
         if self.mix_prob > 0 and self._rng.random() < self.mix_prob:
-            offset = torch.as_tensor(batch["offset"])
-            batch = dict(batch, offset=torch.cat([offset[1:-1:2], offset[-1:]], dim=0))
+            batch = dict(batch, offset=mix3d_offset(batch["offset"]))
         loss = self.loss(batch)
         if self.reducer is not None:
             self.reducer.begin(unused=self._idle_params(batch))

@@ -92,6 +92,17 @@ def test_pipeline_sequence_lengths_and_run_ahead(device):
             assert [torch.equal(g["pred"], r) for g, r in zip(got, ref)] == [True] * k
         got = eng.predict_many((seq[i % 3] for i in range(7)), net_streams=2)     # a generator
         assert len(got) == 7 and all(torch.equal(g["pred"], ref[i % 3]) for i, g in enumerate(got))
+        # a generator that builds fresh device tensors per scene on the caller's stream and keeps no reference: the
+        # side stream must wait for them, and their memory must outlive the voxelizer that reads it
+        host = [(s[0].cpu(), s[1].cpu()) for s in seq]
+
+        def fresh():
+            for i in range(9):
+                c, f = host[i % 3]
+                yield (c.to(device, non_blocking=True) * 1.0, f.to(device, non_blocking=True) + 0.0, seq[i % 3][2], 0.02)
+
+        got = eng.predict_many(fresh(), net_streams=3)
+        assert len(got) == 9 and all(torch.equal(g["pred"], ref[i % 3]) for i, g in enumerate(got))
         got = eng.predict_many([seq[i % 3] for i in range(26)], net_streams=3)      # beyond the run-ahead bound
         assert len(got) == 26 and all(torch.equal(g["pred"], ref[i % 3]) for i, g in enumerate(got))
 

@@ -134,3 +134,55 @@ def test_tensor_walker_reaches_slots_dataclasses_and_containers():
     got = list(engine._tensors_of((vox, [lv]), cuda_only=False))
     assert len(got) == 8 and len({id(t) for t in got}) == 8
     assert list(engine._tensors_of((vox, [lv]))) == []   # CPU tensors are not stream-managed
+
+
+def test_mix3d_offset_is_the_reference_line_for_both_offset_conventions():
+    """language_module.py:212-214 / collate.py:154-157 applied literally; the voxelizer accepts either result."""
+    import torch
+    from segmentation_amd import train
+    import oracle
+    # offsets without a leading zero: samples merged in pairs (an odd last sample stays alone)
+    assert train.mix3d_offset(torch.tensor([3, 5, 9, 12])).tolist() == [5, 12]
+    assert train.mix3d_offset(torch.tensor([3, 5, 9])).tolist() == [5, 9]
+    assert train.mix3d_offset(torch.tensor([3, 5])).tolist() == [5]
+    # offsets as the reference's collate builds them (leading zero, collate.py:96-102): what the reference computes
+    assert train.mix3d_offset(torch.tensor([0, 3, 5, 9, 12])).tolist() == [3, 9, 12]
+    assert train.mix3d_offset(torch.tensor([0, 3, 5, 9])).tolist() == [3, 9]
+    assert train.mix3d_offset(torch.tensor([0, 3, 5])).tolist() == [3, 5]
+    # ... which offset2bincount (misc.py:8-13) reads as the samples [0,3) [3,9) [9,12)
+    assert oracle.offset2bincount(np.array([3, 9, 12])).tolist() == [3, 6, 3]
+
+
+def test_operators_refuse_a_second_host_thread(monkeypatch):
+    """ops._raw_stream() (every launch and every workspace lookup goes through it) remembers the first thread per
+    device and raises from any other, unless M3D_ALLOW_THREADS=1."""
+    import threading
+    import torch
+    from segmentation_amd import ops
+    monkeypatch.setattr(ops, "_OWNER_THREAD", {})
+    monkeypatch.setattr(torch._C, "_cuda_getDevice", lambda: 5, raising=False)
+    monkeypatch.setattr(torch._C, "_cuda_getCurrentRawStream", lambda dev: 1234, raising=False)
+    assert ops._raw_stream() == 1234 and ops._raw_stream() == 1234     # the owner may call as often as it likes
+    result = {}
+
+    def other():
+        try:
+            ops._stream()
+            result["error"] = None
+        except RuntimeError as e:
+            result["error"] = str(e)
+
+    t = threading.Thread(target=other)
+    t.start()
+    t.join()
+    assert result["error"] is not None and "one host thread" in result["error"] and "cuda:5" in result["error"]
+    # another device has no owner yet: the second thread may take it
+    monkeypatch.setattr(torch._C, "_cuda_getDevice", lambda: 6, raising=False)
+    t = threading.Thread(target=other)
+    t.start()
+    t.join()
+    assert result["error"] is None
+    with pytest.raises(RuntimeError):
+        ops._raw_stream()   # ... and the first thread is now the stranger there
+    monkeypatch.setattr(ops, "_ALLOW_THREADS", True)
+    assert ops._raw_stream() == 1234

@@ -59,3 +59,23 @@ def test_static_scratch_refuses_sizes_beyond_the_array(device):
     assert rc == -2 and b"static scratch" in lib.m3d_last_error()
     torch.cuda.synchronize()
     assert float(m.min()) == 7.0 and float(v.max()) == 7.0
+
+
+def test_static_scratch_rejects_invalid_arguments_without_touching_the_outputs(device):
+    from segmentation_amd import _lib
+    lib = _lib.load()
+    torch.cuda.set_device(device)
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    x = torch.ones((16, 32), device=device)
+    m = torch.full((32,), 7.0, device=device)
+    v = torch.full((32,), 7.0, device=device)
+    for n, c in ((0, 32), (-3, 32), (16, 30), (16, 0)):   # no rows; a channel count that is not a multiple of 4 / zero
+        rc = lib.m3d_bn_stats_static(_vp(x), n, c, _vp(m), _vp(v), stream)
+        assert rc < 0 and lib.m3d_last_error(), (n, c)
+    rc = lib.m3d_bn_stats_static(ctypes.c_void_p(0), 16, 32, _vp(m), _vp(v), stream)
+    assert rc < 0
+    torch.cuda.synchronize()
+    assert float(m.min()) == 7.0 and float(v.max()) == 7.0
+    # and the entry point still works afterwards
+    (m0, v0), (m1, v1) = _both(lib, x)
+    assert torch.equal(m0, m1) and torch.equal(v0, v1)
