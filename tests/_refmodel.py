@@ -13,12 +13,20 @@ REF = "/root/reference/mosaic3d"
 
 
 @contextlib.contextmanager
-def reference_modules():
+def reference_modules(install_compat=True, gpu_voxelizer=False):
     """Yields (v1m3, v1m1, ppt, structure) imported from /root/reference with spconv / torch_scatter resolved to
-    segmentation_amd.compat.  Nothing is written to the reference tree; sys.modules is restored afterwards."""
+    segmentation_amd.compat -- or, with install_compat=False, found by the import system itself as the packages
+    spconv/ and torch_scatter/ at the repository root (no call into this package before the reference's own
+    imports).  Nothing is written to the reference tree; sys.modules is restored afterwards."""
     from segmentation_amd import compat
     saved = dict(sys.modules)
-    compat.install(force=True)
+    saved_meta = list(sys.meta_path)
+    if install_compat:
+        compat.install(force=True, gpu_voxelizer=gpu_voxelizer)
+    else:
+        for k in list(sys.modules):
+            if k.split(".")[0] in ("spconv", "torch_scatter"):
+                del sys.modules[k]
     jt = types.ModuleType("jaxtyping")
 
     class _Ann:
@@ -53,9 +61,12 @@ def reference_modules():
     finally:
         sys.dont_write_bytecode = old_flag
         sys.path.remove(REF)
+        sys.meta_path[:] = saved_meta
         for k in list(sys.modules):
             if k not in saved:
                 del sys.modules[k]
+            elif sys.modules[k] is not saved[k]:
+                sys.modules[k] = saved[k]
 
 
 class CpuConvs:

@@ -55,14 +55,14 @@ def build_reference_ppt(v1m3, ppt, cfg, params):
     return model.double().eval()
 
 
-def run():
+def run(install_compat=True):
     import _refmodel
     from oracle import spunet as ospunet
     from segmentation_amd import scenes
     cfg = ospunet.SPUNET34C
     params = ospunet.make_spunet_params(cfg, seed=PARAM_SEED, trained_like=True)
     b = scenes.make_batch(SEEDS, target_voxels=TARGET)
-    with _refmodel.reference_modules() as (v1m3, v1m1, ppt, structure):
+    with _refmodel.reference_modules(install_compat=install_compat) as (v1m3, v1m1, ppt, structure):
         model = build_reference_ppt(v1m3, ppt, cfg, params)
         outs, handles = hooked_outputs(model)
         batch = dict(coord=torch.from_numpy(b["coord"]), feat=torch.from_numpy(b["feat"]).double(),

@@ -185,3 +185,37 @@ def test_deferred_completion_equals_the_blocking_call(device):
             assert torch.equal(got[k], ref[i][k]), k
     with pytest.raises(ValueError):
         ops.voxelize(*args[0], pooling_method="random", defer=True)
+
+
+@pytest.mark.parametrize("name", ["s2", "s3"])
+@pytest.mark.parametrize("hm", ["fnv", "ravel"])
+def test_reference_pooling_signature_on_the_gpu(golden_voxelize, device, name, hm):
+    """compat.gpu_mean_pooling / gpu_random_pooling: the functions compat.install(gpu_voxelizer=True) puts in place of
+    the reference's mean_pooling / random_pooling (structure.py:34-110), called the way Point.sparsify calls them
+    (structure.py:226-237: [batch, grid] integer rows, features) -- against the reference's golden outputs."""
+    from segmentation_amd import compat
+    g = golden_voxelize
+    pre = f"vox_{name}_{hm}_"
+    batch = oracle.offset2batch(g[f"vox_{name}_offset"])
+    coords = torch.from_numpy(np.concatenate([batch[:, None].astype(np.int32), g[pre + "grid_coord"]], 1)).to(device)
+    feat = torch.from_numpy(g[f"vox_{name}_feat"]).to(device)
+    vc, vf, v2p = compat.gpu_mean_pooling(coords, feat, return_inverse=True, hash_method=hm)
+    assert vc.dtype == coords.dtype and v2p.dtype == torch.int64 and vf.dtype == feat.dtype
+    assert np.array_equal(vc.cpu().numpy(), g[pre + "voxel_coords"])
+    assert np.array_equal(v2p.cpu().numpy(), g[pre + "v2p_map"])
+    sp = oracle.sparsify(g[f"vox_{name}_coord"], g[f"vox_{name}_feat"], g[f"vox_{name}_offset"],
+                         float(g[f"vox_{name}_grid"][0]), hash_method=hm)
+    np.testing.assert_allclose(vf.cpu().numpy(), sp["voxel_feats"], rtol=1e-6, atol=1e-7)
+    two = compat.gpu_mean_pooling(coords, feat, return_inverse=False, hash_method=hm)
+    assert len(two) == 2 and torch.equal(two[0], vc)
+    rc, rf, rv = compat.gpu_random_pooling(coords, feat, hash_method=hm)
+    assert torch.equal(rc, vc) and torch.equal(rv, v2p)
+    # every voxel's features are those of one of its own points
+    hit = torch.zeros(rc.shape[0], dtype=torch.bool, device=device)
+    hit[rv[(feat - rf[rv]).abs().sum(1) == 0]] = True
+    assert bool(hit.all())
+    # inputs the wrappers do not take are refused, not mangled
+    with pytest.raises(ValueError):
+        compat.gpu_mean_pooling(coords + 1, feat, hash_method=hm)
+    with pytest.raises(ValueError):
+        compat.gpu_mean_pooling(coords.flip(0), feat, hash_method=hm)
