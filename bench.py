@@ -173,6 +173,11 @@ def main():
     specs = my_scene_specs(args.workload, rank, world, args.scenes_per_rank, args.target_voxels)
     scaling = "strong" if args.workload == "cfg3" else "weak"
 
+    if world > 1:
+        # one process per GPU on a host with about two cores per GPU: the few host-side torch operations of a scene
+        # must not fan out into a thread pool per rank
+        torch.set_num_threads(1)
+
     if args.dry_run:
         dist = None
         if world > 1:
@@ -180,9 +185,11 @@ def main():
             dist.init_process_group("gloo")
         units = float(sum(t for _, t in specs))
         elapsed, total = sharding.reduce_job(1.0 + 0.25 * rank, units, dist, None)
+        lo, mid, hi = sharding.reduce_stats(units, dist, None)
         if rank == 0:
             print(json.dumps(dict(metric="voxels/sec SpUNet fwd", dry_run=True, n_gpus=world, value=total / elapsed,
                                   unit="voxels/s", scaling=scaling, scenes_rank0=[s for s, _ in specs],
+                                  units_per_rank=dict(min=lo, median=mid, max=hi),
                                   config=dict(workload=args.workload))), flush=True)
         if dist is not None:
             dist.barrier()
@@ -298,24 +305,32 @@ def main():
                                               "labels, 768-d features never formed; not the headline")
 
     elapsed, nvox_all = sharding.reduce_job(elapsed, float(nvox), dist, device)
+    # every rank measured the convolution launches of its own scenes on its own GPU: min / median / max over the ranks
+    conv_secs = sum(e0.elapsed_time(e1) * 1e-3 for kind, _, e0, e1, _, _ in prof if kind in ("igemm", "dma", "halo"))
+    conv_rank_ms = sharding.reduce_stats(conv_secs / psteps / max(len(my), 1) * 1e3, dist, device)
 
     if rank == 0:
-        ig = [(f, e0.elapsed_time(e1) * 1e-3) for kind, f, e0, e1, _ in prof if kind in ("igemm", "dma", "halo")]
-        flops = sum(f for f, _ in ig)
-        secs = sum(t for _, t in ig)
+        ig = [(f, e0.elapsed_time(e1) * 1e-3, b) for kind, f, e0, e1, _, b in prof if kind in ("igemm", "dma", "halo")]
+        flops = sum(f for f, _, _ in ig)
+        secs = sum(t for _, t, _ in ig)
+        alg_bytes = sum(b for _, _, b in ig)
         nl = max(len(ig), 1)
         achieved = flops / secs / 1e12 if secs > 0 else 0.0
         # HBM bytes per launch of the same kernels from the committed rocprofv3 --pmc passes (separate runs)
         traffic = None
-        pmc = os.path.join(ROOT, "profiles", f"r02_{args.precision}_conv_pmc.json")
-        if os.path.exists(pmc):
-            traffic = json.load(open(pmc))["all_conv_igemm"]["traffic_bytes_per_launch"]
+        for rnd in ("r03", "r02"):
+            pmc = os.path.join(ROOT, "profiles", f"{rnd}_{args.precision}_conv_pmc.json")
+            if os.path.exists(pmc):
+                traffic = json.load(open(pmc))["all_conv_igemm"]["traffic_bytes_per_launch"]
+                break
         peak = PEAK[args.precision]
         kname = "m3d::conv_igemm_f32_kernel<*>" if args.precision == "f32" else "m3d::conv_igemm_dma_kernel<*>"
         roofline = dict(bound="mfma", achieved=achieved, peak=peak, unit="TFLOP/s", frac=achieved / peak, traffic=traffic,
                         kernel=kname + " (all tile shapes)", launches_per_step=nl // psteps,
                         flop_per_launch=flops / nl, avg_launch_us=secs / nl * 1e6,
+                        algorithmic_bytes_per_launch=alg_bytes / nl,
                         conv_ms_per_scene=secs / psteps / max(len(my), 1) * 1e3,
+                        conv_ms_per_scene_over_ranks=dict(min=conv_rank_ms[0], median=conv_rank_ms[1], max=conv_rank_ms[2]),
                         measured="HIP events around every launch of scenes processed one at a time (a kernel that "
                                  "has the GPU to itself); the timed region overlaps scenes, see config.parallelism",
                         peak_note="dense matrix peak of the instruction issued, in f32-product FLOP/s "
@@ -327,7 +342,9 @@ def main():
             e32 = feature_errors(ref["feat32"], ref["feat64"])
             v2p = torch.as_tensor(ref["sp"]["v2p_map"], dtype=torch.int64)
             parity = dict(reference="CPU oracle in float64 on the same scene; feature_rel_err = per-voxel "
-                                    "||f - ref||_2 / ||ref||_2 (max and mean over voxels); labels per point",
+                                    "||f - ref||_2 / ||ref||_2 (max and mean over voxels) of the 768-d features written "
+                                    "out by forward_features; fused_logit_rel_err = the same measure on the per-voxel "
+                                    "logits of the fused head the timed region runs; labels per point",
                           cpu_oracle_f32=dict(feature_rel_err_max=e32[0], feature_rel_err_mean=e32[1],
                                               label_agreement=float((ref["pred32"] == ref["logits64"].max(1)[1][v2p])
                                                                     .double().mean())))
@@ -339,10 +356,15 @@ def main():
                     assert np.array_equal(vox["v2p_map"].cpu().numpy(), ref["sp"]["v2p_map"])
                     mx, mean = feature_errors(f.cpu(), ref["feat64"])
                     del f
-                    out = e.predict(sc0["coord"], sc0["feat"], sc0["offset"], GRID, fold_head=False)
+                    # the path the timed region runs: last layer + logits + argmax in one kernel (the features
+                    # stay on chip); its per-voxel logits against the float64 ones, its labels per point
+                    out = e.predict(sc0["coord"], sc0["feat"], sc0["offset"], GRID, fold_head=False, return_logits=True)
+                    lmx, lmean = feature_errors(out["voxel_logits"].cpu(), ref["logits64"])
                     parity[p] = dict(feature_rel_err_max=mx, feature_rel_err_mean=mean,
+                                     fused_logit_rel_err_max=lmx, fused_logit_rel_err_mean=lmean,
                                      label_agreement=label_agreement(out["pred"], ref),
                                      voxel_order_and_maps="bit-exact")
+                    del out
                     if p == "f16x3":  # no operand left the f16 range anywhere in this run (status word of the device)
                         parity[p]["f16_range_exceeded"] = bool(ops.f16_status(clear=True))
             cb["label_agreement_vs_gpu"] = parity[args.precision]["label_agreement"]

@@ -550,7 +550,15 @@ def conv_fwd(in0, weight_packed: PackedWeight, sched: Optional[Schedule], n_out,
     if prof is not None:
         ev1.record()
         kind = ("halo" if hcnt is not None else "dma" if sf_in else "igemm") if mfma else "direct"
-        prof.append((kind, 2.0 * npairs * cin * (flop_cout or cout), ev0, ev1, (n_out, cin, cout, k)))
+        # algorithmic bytes of the launch: activations in and out, the weights and the kernel map, each once
+        bpe = 4 if not sf_in else 2 * (2 if in0.terms == FMT_F16_PAIR else in0.terms)
+        n_in0 = in0.n if sf_in else in0.shape[0]
+        n_in1 = 0 if in1 is None else (in1.n if sf_in else in1.shape[0])
+        obytes = (cout * 4 if out is not None else 0) + \
+                 (cout * 2 * (2 if split_terms == FMT_F16_PAIR else split_terms) if split_terms else 0)
+        abytes = (n_in0 * c0 + n_in1 * c1) * bpe + n_out * obytes + k * cout * cin * bpe + \
+                 (0 if sched is None else k * npad * 4) + (n_out * cout * 4 if residual is not None else 0)
+        prof.append((kind, 2.0 * npairs * cin * (flop_cout or cout), ev0, ev1, (n_out, cin, cout, k), abytes))
     return out if not split_terms else (out, out_sp)
 
 
@@ -716,7 +724,7 @@ def head_fused(x: "SplitTensor", w1: "PackedWeight", text: PackedText, scale=Non
     if ev is not None:
         ev[1].record()
         flops = 2.0 * n * text.cmid * (x.c + text.n_classes)
-        PROFILE.append(("head", flops, ev[0], ev[1], (n, x.c, text.n_classes, 1)))
+        PROFILE.append(("head", flops, ev[0], ev[1], (n, x.c, text.n_classes, 1), x.data.numel() + n * 4))
     return label, logits
 
 

@@ -34,3 +34,18 @@ def reduce_job(elapsed_s: float, units: float, dist=None, device=None):
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dist.all_reduce(u, op=dist.ReduceOp.SUM)
     return float(t[0]), float(u[0])
+
+
+def reduce_stats(value: float, dist=None, device=None):
+    """(min, median, max) over the ranks of one number per rank (e.g. the convolution time per scene each rank
+    measured on its own GPU).  `dist` is torch.distributed or None."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return float(value), float(value), float(value)
+    import torch
+    world = dist.get_world_size()
+    mine = torch.tensor([value], dtype=torch.float64, device=device)
+    parts = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(parts, mine)
+    v = sorted(float(p[0]) for p in parts)
+    mid = 0.5 * (v[(world - 1) // 2] + v[world // 2])
+    return v[0], mid, v[-1]

@@ -64,7 +64,7 @@ def test_config0_capture_to_labels_chain(device):
     oc, ofeat = ob["coord"], ob["feat"]
     assert list(ob["offset"]) == [0, oc.shape[0]]
     assert np.array_equal(batch["coord"].cpu().numpy(), oc) and np.array_equal(batch["feat"].cpu().numpy(), ofeat)
-    cfg = dict(ospunet.SPUNET34C, layers=(1, 1, 1, 1, 1, 1, 1, 1))
+    cfg = ospunet.SPUNET34C   # the network of configs/model/spunet34c+ppt.yaml: layers (2, 3, 4, 6, 2, 2, 2, 2)
     params = ospunet.make_spunet_params(cfg, seed=2, trained_like=True)
     emb = torch.from_numpy(scenes.text_embeddings(20, cfg["out_channels"], seed=3))
     off = np.array([0, oc.shape[0]], dtype=np.int64)

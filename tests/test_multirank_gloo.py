@@ -182,3 +182,39 @@ def test_bench_starts_its_own_ranks_dry_run():
             assert len(targets) == 64 and abs(d["value"] * 1.25 - sum(targets)) < 1e-6 * sum(targets)
             parts = sharding.assign_scenes(targets, 2)
             assert d["scenes_rank0"] == parts[0] and len(parts[0]) + len(parts[1]) == 64
+
+
+def test_largest_first_assignment_balances_the_64_scene_job_over_eight_ranks():
+    """configs[2] on a whole node: 64 scenes of 150-250 k voxels over 8 ranks, heaviest rank within 5 % of the lightest."""
+    import bench
+    targets = bench.cfg3_targets()
+    for world in (2, 4, 8):
+        parts = sharding.assign_scenes(targets, world)
+        assert sorted(i for p in parts for i in p) == list(range(64))
+        loads = [sum(targets[i] for i in p) for p in parts]
+        assert max(loads) / min(loads) <= 1.05, (world, loads)
+        assert all(len(p) in (64 // world - 1, 64 // world, 64 // world + 1) for p in parts)
+
+
+def test_bench_dry_run_with_eight_ranks():
+    """The launch, the sharding and both reductions of bench.py with eight ranks on gloo (no kernels)."""
+    import json
+    import subprocess
+    import sys
+    import bench
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["OMP_NUM_THREADS"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--dry-run", "--workload", "cfg3"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    targets = bench.cfg3_targets()
+    parts = sharding.assign_scenes(targets, 8)
+    loads = sorted(float(sum(targets[i] for i in p)) for p in parts)
+    assert d["n_gpus"] == 8 and d["scaling"] == "strong" and d["scenes_rank0"] == parts[0]
+    assert abs(d["value"] * 2.75 - sum(targets)) < 1e-6 * sum(targets)       # slowest rank: 1 + 0.25 * 7 seconds
+    u = d["units_per_rank"]
+    assert u["min"] == loads[0] and u["max"] == loads[-1] and u["median"] == 0.5 * (loads[3] + loads[4])

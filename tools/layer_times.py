@@ -31,7 +31,7 @@ print(f"N0={eng.last_stats['n_voxels']} step(with events)={t0.elapsed_time(t1)/r
 tot_t = tot_f = 0
 for i in range(per):
     ts = [prof[i + r * per][2].elapsed_time(prof[i + r * per][3]) for r in range(reps)]
-    kind, fl, _, _, shp = prof[i]
+    kind, fl, _, _, shp, _ = prof[i]
     t = float(np.median(ts))
     tot_t += t; tot_f += fl
     print(f"{i:3d} {kind:6s} n={shp[0]:7d} cin={shp[1]:4d} cout={shp[2]:4d} k={shp[3]:2d}  {t*1e3:8.1f} us  {fl/1e9:7.2f} GF  {fl/t/1e9:7.1f} TF/s")
