@@ -140,9 +140,17 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3"],
+    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3", "train"],
                     help="cfg2: one ScanNet-scale scene per GPU and step (weak scaling); cfg3: 64 scenes of "
-                         "150-250 k voxels shared out largest-first (strong scaling)")
+                         "150-250 k voxels shared out largest-first (strong scaling); train: configs[3], one "
+                         "optimisation step of train_spunet_multidata_ppt per step (4 scenes per GPU, 300 captions "
+                         "per scene, forward + backward + gradient all-reduce + SGD)")
+    ap.add_argument("--train-precision", default="bf16x3", choices=["f32", "bf16x3", "bf16x6"],
+                    help="--workload train: how forward and input-gradient convolutions form their products")
+    ap.add_argument("--train-voxels", type=int, default=100_000, help="--workload train: scene-generator target per scene")
+    ap.add_argument("--force-reducer", action="store_true",
+                    help="--workload train on one GPU: run the gradient exchange anyway (a process group of one rank "
+                         "over RCCL), so that its packing, hooks, collective and write-back are part of the step")
     ap.add_argument("--target-voxels", type=int, default=TARGET_VOXELS)
     ap.add_argument("--scenes-per-rank", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -170,6 +178,8 @@ def main():
     if world != args.gpus and rank == 0:
         print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; reporting n_gpus={world}", file=sys.stderr)
     from segmentation_amd import sharding
+    if args.workload == "train":
+        return train_main(args, rank, world, local)
     specs = my_scene_specs(args.workload, rank, world, args.scenes_per_rank, args.target_voxels)
     scaling = "strong" if args.workload == "cfg3" else "weak"
 
@@ -397,6 +407,123 @@ def main():
                 feature_rel_err_max=parity["f16x3"]["feature_rel_err_max"],
                 exact_f32_path_feature_rel_err_max=parity.get("f32", {}).get("feature_rel_err_max"),
                 f16_range_exceeded=variants["f16x3"].get("f16_range_exceeded"))
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+TRAIN_SCENES_PER_GPU = 4
+TRAIN_CAPTIONS = 300
+
+
+def train_main(args, rank, world, local):
+    """configs[3]: the optimisation step of train_spunet_multidata_ppt (language_module.py:209-277, CaptionLoss,
+    SGD nesterov + OneCycleLR, data-parallel gradient averaging as configs/trainer/ddp.yaml:4-10) on one batch per
+    rank: 4 synthetic scenes of one dataset condition, 300 captions per scene.  A step = forward + loss + backward
+    (gradient buckets all-reduced over RCCL while backward runs) + optimiser.  Weak scaling: every rank its own batch."""
+    import torch
+    from segmentation_amd import sharding
+    if world > 1:
+        torch.set_num_threads(1)
+    if args.dry_run:
+        # the control flow of a data-parallel step on the CPU: hooks, bucketed asynchronous all-reduce, write-back
+        from segmentation_amd import train
+        dist = None
+        if world > 1:
+            import torch.distributed as dist
+            dist.init_process_group("gloo")
+        torch.manual_seed(0)
+        net = torch.nn.Sequential(torch.nn.Linear(16, 64), torch.nn.ReLU(), torch.nn.Linear(64, 8))
+        red = train.GradientReducer(list(net.parameters()), dist, bucket_bytes=2048, force=dist is not None)
+        opt = torch.optim.SGD(net.parameters(), lr=0.05, momentum=0.9, nesterov=True)
+        x = torch.randn(32, 16, generator=torch.Generator().manual_seed(rank))
+        for _ in range(2):
+            opt.zero_grad(set_to_none=True)
+            red.begin()
+            net(x).square().mean().backward()
+            buckets = red.finish()
+            opt.step()
+        red.close()
+        check = float(sum(p.detach().double().sum() for p in net.parameters()))
+        lo, mid, hi = sharding.reduce_stats(check, dist, None)   # equal parameters on every rank after averaged steps
+        elapsed, total = sharding.reduce_job(1.0 + 0.25 * rank, float(TRAIN_SCENES_PER_GPU * args.train_voxels), dist, None)
+        if rank == 0:
+            print(json.dumps(dict(metric="voxels/sec SpUNet train step", dry_run=True, n_gpus=world, value=total / elapsed,
+                                  unit="voxels/s", scaling="weak", buckets=buckets, replicas_in_sync=abs(hi - lo) < 1e-9,
+                                  config=dict(workload="train"))), flush=True)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an AMD GPU")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_
+        dist = dist_
+        dist.init_process_group("nccl", device_id=device)
+    elif args.force_reducer:
+        import socket
+        import torch.distributed as dist_
+        dist = dist_
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=device)
+    from segmentation_amd import ops, scenes, sparse, spunet, train
+    sparse.set_precision(args.train_precision)
+    torch.manual_seed(0)
+    cfg = spunet.SPUNET34C
+    net = spunet.PPT(spunet.SpUNet(**{k: cfg[k] for k in ("in_channels", "out_channels", "base_channels",
+                                                           "context_channels", "channels", "layers", "conditions")}),
+                     cfg["conditions"], cfg["context_channels"]).to(device)
+    B = TRAIN_SCENES_PER_GPU
+    batch = scenes.make_caption_batch([1000 * rank + b for b in range(B)], args.train_voxels, device,
+                                      captions_per_scene=TRAIN_CAPTIONS, text_dim=cfg["out_channels"],
+                                      rng_seed=100 + rank)
+    step = train.TrainStep(net, total_steps=max(1000, args.steps + args.warmup + 8), dist=dist,
+                           force_reducer=args.force_reducer)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(max(args.warmup, 2)):
+        loss = step(batch)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step(batch)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    with torch.no_grad():
+        nvox = ops.voxelize(batch["coord"], batch["feat"], batch["offset"], GRID)["n_voxels"]
+    elapsed, nvox_all = sharding.reduce_job(elapsed, float(nvox) * args.steps, dist, device)
+    if rank == 0:
+        nparam = sum(p.numel() for p in net.parameters())
+        prec_note = {"f32": "f32 (exact f32 MFMA, forward / input gradient / weight gradient)",
+                     "bf16x3": "f32 storage and accumulation, products from 2-term bf16 splits (3 bf16 MFMA products) in "
+                               "forward, input-gradient and weight-gradient convolutions; norms, loss and optimiser f32",
+                     "bf16x6": "f32 storage and accumulation, 3-term bf16 splits (6 products) in forward and input "
+                               "gradient, 2-term in the weight gradient; norms, loss and optimiser f32"}[args.train_precision]
+        line = dict(metric="voxels/sec SpUNet train step (fwd+bwd+all-reduce+SGD)", value=nvox_all / elapsed,
+                    unit="voxels/s", n_gpus=world, steps=args.steps, warmup=max(args.warmup, 2),
+                    ms_per_step=elapsed / args.steps * 1e3, higher_is_better=True, scaling="weak", vs_baseline=None,
+                    dtype=prec_note, data="synthetic",
+                    config=dict(workload="configs[3]: train_spunet_multidata_ppt step, spunet34c+ppt, caption loss on "
+                                         "precomputed unit text rows, SGD(nesterov)+OneCycleLR",
+                                scenes_per_gpu=B, captions_per_scene=TRAIN_CAPTIONS, voxels_per_gpu=int(nvox),
+                                points_per_gpu=int(batch["coord"].shape[0]), parameters=nparam,
+                                gradient_exchange=("bucketed all-reduce over RCCL overlapped with backward, "
+                                                   f"{len(step.reducer.members)} buckets") if step.reducer else
+                                "none (one rank)", precision=args.train_precision),
+                    loss=float(loss), peak_memory_gib=torch.cuda.max_memory_allocated() / 2 ** 30)
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

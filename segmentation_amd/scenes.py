@@ -80,3 +80,34 @@ def text_embeddings(n_classes, dim=768, seed=1):
     rng = np.random.default_rng(seed)
     e = rng.standard_normal((n_classes, dim)).astype(np.float32)
     return e / np.linalg.norm(e, axis=1, keepdims=True)
+
+
+def make_caption_batch(seeds, target_voxels, device, captions_per_scene=300, text_dim=768, unique_texts=150,
+                       condition="ScanNet", grid_size=0.02, rng_seed=100):
+    """One training batch of the caption-supervised step (train_spunet_multidata_ppt): len(seeds) synthetic scenes of
+    one dataset condition, `captions_per_scene` captions per scene, each a random subset of 100-5000 of the scene's
+    points and a unit text row drawn from `unique_texts` rows (so that rows repeat, as captions do), passed as
+    precomputed `embedding` rows -- the dict mosaic3d/src/data/utils/collate.py:107-179 hands to
+    DenseLanguageLitModule.training_step (language_module.py:209-277)."""
+    import torch
+    from . import train
+    rng = np.random.default_rng(rng_seed)
+    coords, feats, offs, embs, idxs = [], [], [0], [], []
+    for seed in seeds:
+        sc = make_scene(seed=seed, target_voxels=target_voxels, grid_size=grid_size)
+        n = sc["coord"].shape[0]
+        coords.append(sc["coord"])
+        feats.append(sc["feat"])
+        offs.append(offs[-1] + n)
+        rows = rng.normal(size=(unique_texts, text_dim)).astype(np.float32)
+        rows /= np.linalg.norm(rows, axis=1, keepdims=True)
+        uniq = torch.from_numpy(rows).to(device)
+        embs.append([uniq[int(rng.integers(0, unique_texts))] for _ in range(captions_per_scene)])
+        idxs.append([torch.from_numpy(rng.choice(n, size=int(rng.integers(100, min(5000, n) + 1)), replace=False))
+                     for _ in range(captions_per_scene)])
+    pi, co, npc = train.flatten_caption_indices(idxs, torch.tensor(offs))
+    return dict(coord=torch.from_numpy(np.concatenate(coords)).to(device),
+                feat=torch.from_numpy(np.concatenate(feats)).to(device), offset=torch.tensor(offs), grid_size=grid_size,
+                condition=[condition],
+                caption_data=dict(embedding=embs, point_indices=pi.to(device), caption_offsets=co,
+                                  num_points_per_caption=npc))

@@ -221,10 +221,13 @@ class GradientReducer:
     had one (a flag per parameter travels in one small MAX all-reduce) -- otherwise its .grad stays None, as on a
     single GPU."""
 
-    def __init__(self, params, dist, bucket_bytes: int = 32 << 20, overlap: bool = True):
+    def __init__(self, params, dist, bucket_bytes: int = 32 << 20, overlap: bool = True, force: bool = False):
+        """force: run the whole exchange (packing, hooks, asynchronous all-reduce, write-back) even in a process
+        group of one rank, where it changes nothing -- the way to exercise the path on a single GPU."""
         self.dist = dist
         self.params = [p for p in params if p.requires_grad]
         self.world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
+        self.active = self.world > 1 or (force and dist is not None and dist.is_initialized())
         self.overlap = overlap
         order = list(reversed(range(len(self.params))))
         self.bucket_of, self.slices, sizes = {}, {}, []
@@ -246,7 +249,7 @@ class GradientReducer:
         self._pending = self._works = self._launched = None
         self._next = 0
         self._handles = []
-        if self.world > 1 and overlap:
+        if self.active and overlap:
             for i, p in enumerate(self.params):
                 self._handles.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
 
@@ -268,7 +271,7 @@ class GradientReducer:
     def begin(self, unused=()):
         """Call before backward().  `unused`: parameters (objects) known not to receive a gradient in this step on
         this rank (e.g. the norms of the other dataset conditions): their buckets need not wait for them."""
-        if self.world == 1:
+        if not self.active:
             return
         self._pending = [set(m) for m in self.members]
         if unused:
@@ -293,7 +296,7 @@ class GradientReducer:
 
     def finish(self):
         """Call after backward(): averaged gradients are in place when it returns.  Returns the bucket count."""
-        if self.world == 1:
+        if not self.active:
             return 0
         if self._pending is None:
             self.begin()
@@ -344,7 +347,7 @@ class TrainStep:
     def __init__(self, model: torch.nn.Module, total_steps: int, lr: float = 5e-2, momentum: float = 0.9,
                  weight_decay: float = 1e-4, pct_start: float = 0.05, div_factor: float = 10.0,
                  final_div_factor: float = 1000.0, dist=None, use_logit_scale: bool = False, mix_prob: float = 0.0,
-                 seed: int = 0, overlap_allreduce: bool = True, fold_head: bool = True):
+                 seed: int = 0, overlap_allreduce: bool = True, fold_head: bool = True, force_reducer: bool = False):
         self.model = model
         # fold_head: the loss is computed from the input of the backbone's last 1x1x1 convolution
         # (caption_loss_folded); needs a backbone with `final` and `skip_final` (spunet.SpUNet)
@@ -366,8 +369,8 @@ class TrainStep:
                                                          anneal_strategy="cos", div_factor=div_factor,
                                                          final_div_factor=final_div_factor)
         self.reducer = None
-        if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
-            self.reducer = GradientReducer(self.params, dist, overlap=overlap_allreduce)
+        if dist is not None and dist.is_initialized() and (dist.get_world_size() > 1 or force_reducer):
+            self.reducer = GradientReducer(self.params, dist, overlap=overlap_allreduce, force=force_reducer)
 
     def _idle_params(self, batch):
         """Parameters of the per-dataset norms of the conditions this batch does not carry (PDBatchNorm picks

@@ -218,3 +218,22 @@ def test_bench_dry_run_with_eight_ranks():
     assert abs(d["value"] * 2.75 - sum(targets)) < 1e-6 * sum(targets)       # slowest rank: 1 + 0.25 * 7 seconds
     u = d["units_per_rank"]
     assert u["min"] == loads[0] and u["max"] == loads[-1] and u["median"] == 0.5 * (loads[3] + loads[4])
+
+
+def test_bench_train_workload_dry_run_two_ranks():
+    """`bench.py --workload train --gpus 2 --dry-run`: two ranks run the data-parallel step's control flow on gloo
+    (hooks, bucketed asynchronous all-reduce, write-back, optimiser) and end with identical parameters."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run", "--workload", "train"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["dry_run"] and d["scaling"] == "weak" and d["buckets"] >= 2
+    assert d["replicas_in_sync"] is True
+    assert abs(d["value"] * 1.25 - 2 * 4 * 100_000) < 1e-6
