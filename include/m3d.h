@@ -438,6 +438,74 @@ int m3d_head_fused_terms(const void* d_in_split, int cin, int64_t n, int terms, 
                          const float* d_shift, int cmid, const void* d_text_packed, int classes_padded, int n_classes,
                          float* d_logits, int64_t ldl, int32_t* d_voxel_label, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * A whole network enqueued by one call.  Replaces the layer-by-layer walk of SpUNetBase.forward
+ * (mosaic3d/src/models/networks/spunet/spconv_unet_v1m3_pdnorm.py:380-414: conv_input, the encoder stages, the decoder
+ * stages with their skip concatenations, final) and of the head (clip_alignment_loss.py:138-147,
+ * language_module.py:202-207,328) for a caller that has folded the norms and packed the weights once: per scene it
+ * hands over the kernel maps of its levels, the level-0 input rows and one arena, and every layer is launched from
+ * inside the library through the entry points above (same kernels, same tile plans, same bits as layer-by-layer calls).
+ *
+ * Description (built once): values = the tensors of the network (value 0 is the input, external), layers = the
+ * operations in launch order.  A layer reads in0 (and in1, the second K-slab of a concatenated input, and an f32
+ * residual) and writes an f32 output and/or a split-format output.  Values live in the arena; a value's memory is
+ * reused by later values of its level once its last reader has been enqueued (everything runs on one stream). */
+#define M3D_NET_CONV 0           /* m3d_conv_fwd_sf32 / m3d_conv_fwd_f32, by the format of in0 */
+#define M3D_NET_SPLIT 1          /* m3d_split_f32: f32 rows -> the split format of out_split */
+#define M3D_NET_HEAD 2           /* m3d_head_fused_terms: last 1x1 layer + text logits + argmax */
+#define M3D_NET_ARGMAX 3         /* m3d_argmax_rows over an f32 logits value (in0; its channel count is the row stride) */
+#define M3D_NET_GATHER_LABELS 4  /* m3d_gather_labels: per-point labels through the v2p map */
+#define M3D_NET_DENSE 0          /* schedule kinds of a convolution: none (1x1), */
+#define M3D_NET_SUBM 1           /* the submanifold map of the output level, */
+#define M3D_NET_DOWN 2           /* the strided map from the level above (finer) into the output level, */
+#define M3D_NET_UP 3             /* its inverse, from the coarser level into the output level */
+typedef struct {
+  int32_t level;     /* resolution level of the rows (0 = finest) */
+  int32_t channels;
+  int32_t format;    /* 0 = f32 rows [rows][channels]; 1, 2, 3, 4 = the split format of that code (see m3d_conv_fwd_sf32) */
+} m3d_net_value_t;
+typedef struct {
+  int32_t op;                      /* M3D_NET_* operation */
+  int32_t in0, in1, residual;      /* value ids; in1 / residual = -1 for none */
+  int32_t out_f32, out_split;      /* value ids or -1 */
+  int32_t sched;                   /* M3D_NET_DENSE / SUBM / DOWN / UP (convolutions) */
+  int32_t k, cout, c0, c1, relu;   /* convolution shape (c0, c1 = channels of in0, in1); HEAD: cout = feature channels */
+  int32_t precision;               /* M3D_PREC_* of the packed weight (used when in0 is f32 rows) */
+  int32_t n_classes, classes_padded;  /* HEAD / ARGMAX */
+  const void* weight;              /* m3d_conv_pack_weight output (CONV, HEAD) */
+  const float* scale;              /* [cout] or NULL */
+  const float* shift;              /* [cout] or NULL */
+  const void* text;                /* HEAD: m3d_head_pack_text_terms output */
+} m3d_net_layer_t;
+typedef struct {
+  const int32_t* nbr;
+  const int32_t* out_row;
+  const uint32_t* tile_mask;
+  const int32_t* tile_order;  /* or NULL */
+  int64_t n, npad;            /* output rows, schedule length */
+  int32_t k;                  /* kernel offsets of the map */
+} m3d_net_sched_t;
+typedef struct {
+  m3d_net_sched_t subm;  /* 3x3x3 map of the level */
+  m3d_net_sched_t down;  /* 2x2x2 stride-2 map of this level into the next coarser one (unused on the last level) */
+  m3d_net_sched_t up;    /* its inverse: the coarser level back into this one */
+} m3d_net_maps_t;
+/* m3d_net_create checks the description (ids, levels, shapes, formats) and assigns arena slots; *out_net is freed by
+ * m3d_net_destroy.  The pointers inside the layers (weights, scale / shift vectors, packed text) must stay valid.
+ * m3d_net_arena_bytes(net, level_rows[n_levels]): bytes of arena m3d_net_run needs for a scene with these row counts
+ * (it includes the largest convolution workspace).
+ * m3d_net_run: maps[n_levels], level_rows[n_levels], d_input = value 0 ([level_rows[0]][channels] f32), d_arena
+ * 256-byte aligned.  HEAD / ARGMAX write d_voxel_label [level_rows[0]] and, if d_logits != NULL, the per-voxel logits
+ * (row stride ldl floats); GATHER_LABELS writes d_point_label [n_points] through d_v2p_map.  Nothing is allocated and
+ * nothing synchronises. */
+int m3d_net_create(const m3d_net_layer_t* layers, int n_layers, const m3d_net_value_t* values, int n_values, int n_levels,
+                   void** out_net);
+void m3d_net_destroy(void* net);
+size_t m3d_net_arena_bytes(const void* net, const int64_t* level_rows);
+int m3d_net_run(const void* net, const m3d_net_maps_t* maps, const int64_t* level_rows, const float* d_input, void* d_arena,
+                size_t arena_bytes, const int64_t* d_v2p_map, int64_t n_points, int32_t* d_voxel_label,
+                int64_t* d_point_label, float* d_logits, int64_t ldl, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

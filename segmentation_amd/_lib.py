@@ -75,7 +75,33 @@ SIGNATURES = {
     "m3d_head_pack_text_terms": (_int, [_vp, _int, _int, _int, _int, _vp, _vp]),
     "m3d_head_fused_terms": (_int, [_vp, _int, _i64, _int, _vp, _vp, _vp, _int, _vp, _int, _int, _vp, _i64, _vp, _vp]),
     "m3d_head_fused_sf32": (_int, [_vp, _int, _i64, _vp, _vp, _vp, _int, _vp, _int, _int, _vp, _i64, _vp, _vp]),
+    "m3d_net_create": (_int, [_vp, _int, _vp, _int, _int, ctypes.POINTER(_vp)]),
+    "m3d_net_destroy": (None, [_vp]),
+    "m3d_net_arena_bytes": (_sz, [_vp, ctypes.POINTER(_i64)]),
+    "m3d_net_run": (_int, [_vp, _vp, ctypes.POINTER(_i64), _vp, _vp, _sz, _vp, _i64, _vp, _vp, _vp, _i64, _vp]),
 }
+
+_i32 = ctypes.c_int32
+
+
+class NetValue(ctypes.Structure):      # m3d_net_value_t
+    _fields_ = [("level", _i32), ("channels", _i32), ("format", _i32)]
+
+
+class NetLayer(ctypes.Structure):      # m3d_net_layer_t
+    _fields_ = [("op", _i32), ("in0", _i32), ("in1", _i32), ("residual", _i32), ("out_f32", _i32), ("out_split", _i32),
+                ("sched", _i32), ("k", _i32), ("cout", _i32), ("c0", _i32), ("c1", _i32), ("relu", _i32),
+                ("precision", _i32), ("n_classes", _i32), ("classes_padded", _i32),
+                ("weight", _vp), ("scale", _vp), ("shift", _vp), ("text", _vp)]
+
+
+class NetSched(ctypes.Structure):      # m3d_net_sched_t
+    _fields_ = [("nbr", _vp), ("out_row", _vp), ("tile_mask", _vp), ("tile_order", _vp), ("n", _i64), ("npad", _i64),
+                ("k", _i32)]
+
+
+class NetMaps(ctypes.Structure):       # m3d_net_maps_t
+    _fields_ = [("subm", NetSched), ("down", NetSched), ("up", NetSched)]
 
 _lib = None
 

@@ -22,7 +22,9 @@ import os
 import time
 import torch
 
-from . import ops, sparse
+import ctypes
+
+from . import _lib, ops, sparse
 
 
 def _fold_norm(sd: Dict[str, torch.Tensor], prefix: str, cond_idx: int, context: Optional[torch.Tensor],
@@ -82,6 +84,88 @@ class _Level:
     """Kernel maps of one resolution level."""
     __slots__ = ("indices", "shape", "n", "subm", "down", "up", "pair_subm", "pair_fwd", "pair_bwd",
                  "next_indices", "next_shape", "n_next")
+
+
+class _SymLevel:
+    """A level of the traced network: schedules are (kind, output level) tags, row counts are not known."""
+    __slots__ = ("subm", "down", "up", "n", "n_next")
+
+    def __init__(self, l):
+        self.subm, self.down, self.up, self.n, self.n_next = ("subm", l), ("down", l + 1), ("up", l), None, None
+
+
+class _Trace:
+    """Layer list of the network as m3d_net_create takes it (include/m3d.h), recorded by running the engine's own
+    forward code on value ids instead of tensors."""
+    OPS = dict(conv=0, split=1, head=2, argmax=3, gather=4)
+    SCHED = {None: 0, "subm": 1, "down": 2, "up": 3}
+
+    def __init__(self, in_channels):
+        self.values = [(0, in_channels, 0)]   # (level, channels, format); value 0 = the voxel features
+        self.layers = []
+        self.keep = []                        # tensors the layer records point into
+
+    def new(self, level, channels, fmt):
+        self.values.append((level, channels, fmt))
+        return len(self.values) - 1
+
+    def add(self, op, in0, in1=None, residual=None, out_f32=None, out_split=None, sched=None, k=1, cout=0, c0=0, c1=0,
+            relu=False, precision=0, n_classes=0, classes_padded=0, weight=None, scale=None, shift=None, text=None):
+        i = lambda v: -1 if v is None else int(v)
+        p = lambda t: None if t is None else t.data_ptr()
+        self.keep += [t for t in (weight, scale, shift, text) if t is not None]
+        self.layers.append(_lib.NetLayer(self.OPS[op], i(in0), i(in1), i(residual), i(out_f32), i(out_split),
+                                         self.SCHED[sched], k, cout, c0, c1, int(bool(relu)), precision, n_classes,
+                                         classes_padded, p(weight), p(scale), p(shift), p(text)))
+
+
+class _NetPlan:
+    """The engine's network as one library call per scene (m3d_net_run)."""
+
+    def __init__(self, trace, n_levels, classes_padded):
+        self.lib = _lib.load()
+        self.keep = trace.keep
+        self.n_levels, self.classes_padded = n_levels, classes_padded
+        layers = (_lib.NetLayer * len(trace.layers))(*trace.layers)
+        values = (_lib.NetValue * len(trace.values))(*[_lib.NetValue(*v) for v in trace.values])
+        handle = ctypes.c_void_p()
+        _lib.check(self.lib.m3d_net_create(layers, len(trace.layers), values, len(trace.values), n_levels,
+                                           ctypes.byref(handle)), "m3d_net_create")
+        self.handle, self.n_layers = handle, len(trace.layers)
+        self.rows = (ctypes.c_int64 * n_levels)()
+        self.maps = (_lib.NetMaps * n_levels)()
+
+    def __del__(self):
+        if getattr(self, "handle", None):
+            self.lib.m3d_net_destroy(self.handle)
+            self.handle = None
+
+    @staticmethod
+    def _fill(dst, sched):
+        dst.nbr, dst.out_row, dst.tile_mask = sched.nbr.data_ptr(), sched.out_row.data_ptr(), sched.tile_mask.data_ptr()
+        dst.tile_order = None if sched.tile_order is None else sched.tile_order.data_ptr()
+        dst.n, dst.npad, dst.k = sched.n, sched.npad, sched.k
+
+    def run(self, voxel_feats, levels, v2p_map, n_points, want_logits):
+        assert len(levels) == self.n_levels
+        for l, lv in enumerate(levels):
+            self.rows[l] = lv.n
+            self._fill(self.maps[l].subm, lv.subm)
+            if lv.down is not None:
+                self._fill(self.maps[l].down, lv.down)
+                self._fill(self.maps[l].up, lv.up)
+        dev = voxel_feats.device
+        n0 = levels[0].n
+        arena = torch.empty((self.lib.m3d_net_arena_bytes(self.handle, self.rows),), dtype=torch.uint8, device=dev)
+        vlabel = torch.empty((n0,), dtype=torch.int32, device=dev)
+        plabel = torch.empty((n_points,), dtype=torch.int64, device=dev)
+        logits = torch.empty((n0, self.classes_padded), dtype=torch.float32, device=dev) if want_logits else None
+        ops._need_cuda(voxel_feats, v2p_map)
+        rc = self.lib.m3d_net_run(self.handle, self.maps, self.rows, ops._ptr(voxel_feats), ops._ptr(arena), arena.numel(),
+                                  ops._ptr(v2p_map), n_points, ops._ptr(vlabel), ops._ptr(plabel), ops._ptr(logits),
+                                  self.classes_padded, ops._stream())
+        _lib.check(rc, "m3d_net_run")
+        return vlabel, plabel, logits
 
 
 class SpUNetEngine:
@@ -156,6 +240,11 @@ class SpUNetEngine:
                     for s in range(self.num_stages)]
         self.final = conv("final.weight", None, "final.bias")
         self.final_head = None   # `final` in the format of the fused head where that differs from the backbone's
+        # the network as one library call per scene (m3d_net_run) instead of one call per layer from here: same
+        # kernels and results, a fraction of the host time.  M3D_NET_PLAN=0 keeps the layer-by-layer path.
+        self.use_plan = os.environ.get("M3D_NET_PLAN", "1") != "0"
+        self._trace = None
+        self._plan = None
         self.text = None
         self.n_classes = 0
         self.last_stats = {}
@@ -187,6 +276,7 @@ class SpUNetEngine:
     def _set_text_embeddings(self, emb: torch.Tensor):
         emb = emb.detach().float().to(self.device)
         self._emb = emb
+        self._plan = None
         if self._twin is not None:
             self._twin.set_text_embeddings(emb)
         c, d = emb.shape
@@ -275,6 +365,8 @@ class SpUNetEngine:
     # kernel and an f32 copy is written only where a residual or the caller needs it.
     def _conv(self, c, x, sched, n, x2=None, residual=None, relu=False, need_f32=True, need_sf=True):
         T = self._terms
+        if self._trace is not None:
+            return self._conv_traced(c, x, sched, x2, residual, relu, need_f32, need_sf)
         if T == 0:
             out = ops.conv_fwd(x[0], c.w, sched, n, in1=None if x2 is None else x2[0], scale=c.scale,
                                shift=c.shift, residual=residual, relu=relu)
@@ -286,6 +378,54 @@ class SpUNetEngine:
             r = ops.conv_fwd(x[0], c.w, sched, n, scale=c.scale, shift=c.shift, residual=residual, relu=relu,
                              want_f32=need_f32, split_terms=T if need_sf else 0)
         return r if need_sf else (r, None)
+
+    def _conv_traced(self, c, x, sched, x2, residual, relu, need_f32, need_sf):
+        """_conv on value ids: records the layer (same choice of inputs and outputs as the code above)."""
+        T, tr = self._terms, self._trace
+        if T == 0:
+            in0, in1, want_f32, split = x[0], None if x2 is None else x2[0], True, 0
+        elif x[1] is not None and c.w.precision != "f32":
+            in0, in1, want_f32, split = x[1], None if x2 is None else x2[1], need_f32, (T if need_sf else 0)
+        else:
+            in0, in1, want_f32, split = x[0], None, need_f32, (T if need_sf else 0)
+        level = tr.values[in0][0] if sched is None else sched[1]
+        out_f32 = tr.new(level, c.cout, 0) if want_f32 else None
+        out_sf = tr.new(level, c.cout, split) if split else None
+        tr.add("conv", in0, in1, residual, out_f32, out_sf, None if sched is None else sched[0], c.w.k, c.cout,
+               tr.values[in0][1], 0 if in1 is None else tr.values[in1][1], relu, ops.PRECISION[c.w.precision],
+               weight=c.w.data, scale=c.scale, shift=c.shift)
+        return (out_f32, out_sf)
+
+    def _build_plan(self):
+        """Trace backbone + head (the default call: labels, optionally logits) into a _NetPlan."""
+        nl = self.num_stages + 1
+        tr = _Trace(self.stem.w.cin)
+        levels = [_SymLevel(l) for l in range(nl)]
+        self._trace = tr
+        try:
+            if self.text_fused is not None:
+                fin = self.final_head if self.final_head is not None else self.final
+                if self._head_terms != self._terms:
+                    x = self.backbone(0, levels, last_f32=True)
+                    xs = tr.new(0, tr.values[x[0]][1], self._head_terms)
+                    tr.add("split", x[0], out_split=xs)
+                else:
+                    xs = self.backbone(0, levels)[1]
+                tr.add("head", xs, cout=self.text_fused.cmid, n_classes=self.text_fused.n_classes,
+                       classes_padded=self.text_fused.classes_padded, weight=fin.w.data, scale=fin.scale, shift=fin.shift,
+                       text=self.text_fused.data)
+                cpad = self.text_fused.classes_padded
+            else:
+                x = self.backbone(0, levels)
+                pair = self._conv(self.final, x, None, None, need_f32=self._terms == 0, need_sf=self._terms != 0)
+                src = (None, pair[1]) if self._terms else (pair[0], None)
+                logits = self._conv(self.text, src, None, None, need_f32=True, need_sf=False)[0]
+                tr.add("argmax", logits, n_classes=self.n_classes)
+                cpad = self.text.cout
+            tr.add("gather", 0)
+        finally:
+            self._trace = None
+        return _NetPlan(tr, nl, cpad)
 
     def _block(self, blk, x, sched, n, x2=None, last_needs_f32=True):
         """BasicBlock with fused epilogues; (x, x2) are the two K-slabs of a concatenated input."""
@@ -551,6 +691,16 @@ class SpUNetEngine:
         else:
             vox, levels, n_points = maps
         self.last_stats = dict(n_points=n_points, n_voxels=[levels[l].n for l in range(len(levels))])
+        if self.use_plan and not fold_head and not return_features and ops.PROFILE is None and not self.halo_levels \
+                and not (return_logits and self.label_head is not None):
+            # the whole network and the head as one library call
+            if self._plan is None:
+                self._plan = self._build_plan()
+            vlabel, plabel, logits = self._plan.run(vox["voxel_feats"], levels, vox["v2p_map"], n_points, return_logits)
+            out = dict(pred=plabel, voxel_pred=vlabel, v2p_map=vox["v2p_map"], n_voxels=vox["n_voxels"])
+            if return_logits:
+                out["voxel_logits"] = logits[:, :self.n_classes]
+            return out
         # the fused head serves a call unless it asks for the features, or for logits while the head's precision is a
         # labels-only choice (label_head)
         if self.text_fused is not None and not fold_head and not return_features and \
