@@ -506,6 +506,36 @@ int m3d_net_run(const void* net, const m3d_net_maps_t* maps, const int64_t* leve
                 size_t arena_bytes, const int64_t* d_v2p_map, int64_t n_points, int32_t* d_voxel_label,
                 int64_t* d_point_label, float* d_logits, int64_t ldl, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Kernel maps and tile schedules of all resolution levels of a scene in two calls.  Replaces what SpUNetBase.forward
+ * has spconv build on the first use of every indice_key (spconv_unet_v1m3_pdnorm.py:98-117 "subm{s}", :154-161
+ * "spconv{s}" and its reuse by the inverse convolutions :184-190, :205-212 "stem") for a caller that wants one
+ * library call per phase instead of one per map and schedule; every step goes through m3d_strided_rulebook,
+ * m3d_subm_rulebook, m3d_build_schedule and m3d_schedule_tile_order in the order a level-by-level caller uses them
+ * (same bits).
+ *   m3d_levels_begin:  the chain of stride-2 maps (level l -> l + 1; the row count of a level stays on the device,
+ *                      d_counts[l] = rows of level l + 1) and the submanifold map + schedule of level 0.  Only
+ *                      levels[0].n is read; the per-row outputs of every level must hold levels[0].n rows.
+ *   m3d_levels_finish: after the caller has read d_counts back and filled levels[l].n: submanifold maps + schedules
+ *                      of levels >= 1 and the schedules of the strided maps and of their inverses. */
+typedef struct {
+  const int32_t* indices;   /* [n][4]; level l + 1 reads next_indices of level l */
+  int64_t n;                /* rows of the level */
+  int64_t shape[3];         /* spatial shape of the level */
+  int32_t* next_indices;    /* [levels[0].n][4] coordinates of the next coarser level (unused on the last level) */
+  int32_t* pair_fwd;        /* [8][ld] */
+  int32_t* pair_bwd;        /* [8][ld] */
+  int64_t ld;               /* column stride of pair_fwd / pair_bwd = levels[0].n */
+  int32_t* pair_subm;       /* [27][n] */
+  int32_t subm_mode;        /* m3d_build_schedule mode of the submanifold schedule */
+  struct { int32_t* nbr; int32_t* out_row; uint32_t* tile_mask; int32_t* tile_order; } subm, down, up;
+  /* subm: [27][npad(n)], [npad(n)], [npad(n)/32], [npad(n)/128] or NULL; down: [8][npad(n_next)] ...; up: [8][npad(n)] ... */
+} m3d_level_t;
+size_t m3d_levels_workspace_bytes(const m3d_level_t* levels, int n_levels, int batch_size);
+int m3d_levels_begin(const m3d_level_t* levels, int n_levels, int batch_size, int64_t* d_counts, void* d_ws, size_t ws_bytes,
+                     void* stream);
+int m3d_levels_finish(const m3d_level_t* levels, int n_levels, int batch_size, void* d_ws, size_t ws_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -79,6 +79,9 @@ SIGNATURES = {
     "m3d_net_destroy": (None, [_vp]),
     "m3d_net_arena_bytes": (_sz, [_vp, ctypes.POINTER(_i64)]),
     "m3d_net_run": (_int, [_vp, _vp, ctypes.POINTER(_i64), _vp, _vp, _sz, _vp, _i64, _vp, _vp, _vp, _i64, _vp]),
+    "m3d_levels_workspace_bytes": (_sz, [_vp, _int, _int]),
+    "m3d_levels_begin": (_int, [_vp, _int, _int, _vp, _vp, _sz, _vp]),
+    "m3d_levels_finish": (_int, [_vp, _int, _int, _vp, _sz, _vp]),
 }
 
 _i32 = ctypes.c_int32
@@ -132,3 +135,13 @@ def check(rc, what):
     if rc != 0:
         msg = load().m3d_last_error().decode("utf-8", "replace")
         raise M3DError(f"{what} failed (code {rc}): {msg}")
+
+
+class LevelSched(ctypes.Structure):    # the schedule outputs inside m3d_level_t
+    _fields_ = [("nbr", _vp), ("out_row", _vp), ("tile_mask", _vp), ("tile_order", _vp)]
+
+
+class Level(ctypes.Structure):         # m3d_level_t
+    _fields_ = [("indices", _vp), ("n", _i64), ("shape", _i64 * 3), ("next_indices", _vp), ("pair_fwd", _vp),
+                ("pair_bwd", _vp), ("ld", _i64), ("pair_subm", _vp), ("subm_mode", _i32),
+                ("subm", LevelSched), ("down", LevelSched), ("up", LevelSched)]

@@ -142,8 +142,12 @@ class _NetPlan:
 
     @staticmethod
     def _fill(dst, sched):
-        dst.nbr, dst.out_row, dst.tile_mask = sched.nbr.data_ptr(), sched.out_row.data_ptr(), sched.tile_mask.data_ptr()
-        dst.tile_order = None if sched.tile_order is None else sched.tile_order.data_ptr()
+        if isinstance(sched, ops.ArenaSchedule):
+            dst.nbr, dst.out_row, dst.tile_mask = sched.ptr(sched.o_nbr), sched.ptr(sched.o_row), sched.ptr(sched.o_mask)
+            dst.tile_order = sched.ptr(sched.o_order)
+        else:
+            dst.nbr, dst.out_row, dst.tile_mask = sched.nbr.data_ptr(), sched.out_row.data_ptr(), sched.tile_mask.data_ptr()
+            dst.tile_order = None if sched.tile_order is None else sched.tile_order.data_ptr()
         dst.n, dst.npad, dst.k = sched.n, sched.npad, sched.k
 
     def run(self, voxel_feats, levels, v2p_map, n_points, want_logits):
@@ -243,6 +247,8 @@ class SpUNetEngine:
         # the network as one library call per scene (m3d_net_run) instead of one call per layer from here: same
         # kernels and results, a fraction of the host time.  M3D_NET_PLAN=0 keeps the layer-by-layer path.
         self.use_plan = os.environ.get("M3D_NET_PLAN", "1") != "0"
+        # kernel maps and schedules of all levels through m3d_levels_begin / m3d_levels_finish (two library calls)
+        self.use_level_chain = os.environ.get("M3D_LEVEL_CHAIN", "1") != "0"
         self._trace = None
         self._plan = None
         self.text = None
@@ -326,6 +332,23 @@ class SpUNetEngine:
     def build_levels_begin(self, voxel_coords, spatial_shape, batch_size=1):
         """First half of build_levels: enqueues the chain of strided maps and the level-0 map and schedule, and
         returns the function that does the rest (it waits for the level counts, nothing else)."""
+        if self.use_level_chain and not self.halo_levels:
+            # all maps and schedules through two library calls (same bits as the level-by-level calls below)
+            modes = [self.sched_modes[min(l, len(self.sched_modes) - 1)] for l in range(self.num_stages + 1)]
+            done = ops.level_chain_begin(voxel_coords, spatial_shape, batch_size, self.num_stages, modes, self.tile_order)
+
+            def finish():
+                levels = []
+                for d in done():
+                    lv = _Level()
+                    lv.indices, lv.shape, lv.n, lv.pair_subm, lv.subm = d["indices"], d["shape"], d["n"], d["pair_subm"], d["subm"]
+                    lv.pair_fwd, lv.pair_bwd = d.get("pair_fwd"), d.get("pair_bwd")
+                    lv.next_indices, lv.next_shape, lv.n_next = d.get("next_indices"), d.get("next_shape"), d.get("n_next", 0)
+                    lv.down, lv.up = d.get("down"), d.get("up")
+                    levels.append(lv)
+                return levels
+
+            return finish
         chain_done = ops.strided_chain(voxel_coords, spatial_shape, batch_size, self.num_stages, defer=True)
         # level 0 needs nothing from the chain: its map and schedule keep the GPU busy while the counts travel
         pair0 = ops.subm_rulebook(voxel_coords, list(spatial_shape), batch_size)

@@ -281,6 +281,161 @@ class Schedule:
     tile_order: object = None  # optional [npad/128] i32: 128-row tiles, heaviest first (m3d_schedule_tile_order)
 
 
+class ArenaSchedule:
+    """A Schedule whose arrays are slices of one int32 buffer (the level-chain entry points write all maps and
+    schedules of a scene into two such buffers): the device addresses are at hand without creating a tensor per
+    array; the tensors are made on request."""
+    __slots__ = ("buf", "o_nbr", "o_row", "o_mask", "o_order", "n", "npad", "k", "halo", "_npairs")
+
+    def __init__(self, buf, o_nbr, o_row, o_mask, o_order, n, npad, k):
+        self.buf, self.o_nbr, self.o_row, self.o_mask, self.o_order = buf, o_nbr, o_row, o_mask, o_order
+        self.n, self.npad, self.k, self.halo, self._npairs = n, npad, k, None, None
+
+    def ptr(self, off):
+        return None if off < 0 else self.buf.data_ptr() + 4 * off
+
+    @property
+    def nbr(self):
+        return self.buf[self.o_nbr:self.o_nbr + self.k * self.npad].view(self.k, self.npad)
+
+    @property
+    def out_row(self):
+        return self.buf[self.o_row:self.o_row + self.npad]
+
+    @property
+    def tile_mask(self):
+        return self.buf[self.o_mask:self.o_mask + self.npad // 32]
+
+    @property
+    def tile_order(self):
+        return None if self.o_order < 0 else self.buf[self.o_order:self.o_order + self.npad // 128]
+
+
+class _Carver:
+    """Offsets (in int32 elements, 256-byte aligned) of consecutive arrays inside one buffer."""
+
+    def __init__(self):
+        self.off = 0
+
+    def take(self, count):
+        o = self.off
+        self.off += (int(count) + 63) // 64 * 64
+        return o
+
+
+def level_chain_begin(indices, spatial_shape, batch_size, depth, subm_modes, tile_order=True):
+    """Kernel maps and schedules of all levels through m3d_levels_begin / m3d_levels_finish (two library calls per
+    scene).  Enqueues the chain of strided maps and level 0's submanifold map + schedule, starts the copy of the
+    level counts to pinned memory and returns finish(): it waits for that copy alone, enqueues the rest and returns
+    a list of per-level dicts (indices, shape, n, pair_subm, subm; and, except on the last level, pair_fwd, pair_bwd,
+    next_indices, next_shape, n_next, down, up) -- the same maps and schedules, bit for bit, as subm_rulebook /
+    strided_chain / build_schedule give level by level."""
+    lib = _lib.load()
+    _need_cuda(indices)
+    indices = indices.contiguous()
+    assert indices.dtype == torch.int32 and indices.dim() == 2 and indices.shape[1] == 4
+    n0, dev, nl = indices.shape[0], indices.device, depth + 1
+    if n0 == 0:
+        raise ValueError("level_chain needs at least one voxel")
+    npad0 = lib.m3d_schedule_npad(n0)
+    c = _Carver()
+    o_next = [c.take(4 * n0) for _ in range(depth)]
+    o_pf = [c.take(8 * n0) for _ in range(depth)]
+    o_pb = [c.take(8 * n0) for _ in range(depth)]
+    o_pair0, o_nbr0, o_row0, o_mask0 = c.take(27 * n0), c.take(27 * npad0), c.take(npad0), c.take(npad0 // 32)
+    o_ord0 = c.take(npad0 // 128) if tile_order else -1
+    buf = torch.empty((c.off,), dtype=torch.int32, device=dev)
+    base = buf.data_ptr()
+    counts = torch.empty((max(depth, 1),), dtype=torch.int64, device=dev)
+    L = (_lib.Level * nl)()
+    shape = [int(v) for v in spatial_shape]
+    shapes = []
+    for l in range(nl):
+        v = L[l]
+        shapes.append(list(shape))
+        v.indices = indices.data_ptr() if l == 0 else base + 4 * o_next[l - 1]
+        v.n = n0 if l == 0 else 0
+        v.shape[0], v.shape[1], v.shape[2] = shape
+        v.subm_mode = int(subm_modes[min(l, len(subm_modes) - 1)])
+        if l < depth:
+            v.next_indices, v.pair_fwd, v.pair_bwd, v.ld = base + 4 * o_next[l], base + 4 * o_pf[l], base + 4 * o_pb[l], n0
+        shape = [d // 2 for d in shape]
+    v = L[0]
+    v.pair_subm = base + 4 * o_pair0
+    v.subm.nbr, v.subm.out_row, v.subm.tile_mask = base + 4 * o_nbr0, base + 4 * o_row0, base + 4 * o_mask0
+    v.subm.tile_order = None if o_ord0 < 0 else base + 4 * o_ord0
+    ws = _workspace(lib.m3d_levels_workspace_bytes(L, nl, int(batch_size)), dev)
+    rc = lib.m3d_levels_begin(L, nl, int(batch_size), _ptr(counts), _ptr(ws), ws.numel(), _stream())
+    _lib.check(rc, "m3d_levels_begin")
+    slot = _PINNED_COUNTS.setdefault((dev.index, max(depth, 1)), [])  # one pinned buffer per call in flight
+    pinned = slot.pop() if slot else torch.empty((max(depth, 1),), dtype=torch.int64, pin_memory=True)
+    if depth:
+        pinned.copy_(counts, non_blocking=True)
+    landed = torch.cuda.Event()
+    landed.record()
+
+    def finish():
+        landed.synchronize()
+        m = pinned.tolist() if depth else []
+        slot.append(pinned)
+        ns = [n0] + [int(x) for x in m[:depth]]
+        for l in range(1, nl):
+            if ns[l] <= 0:
+                raise ValueError(f"strided_rulebook: level {l - 1} has no output voxel")
+        npad = [lib.m3d_schedule_npad(n) for n in ns]
+        c2 = _Carver()
+        o_pair, o_sub, o_dn, o_up = {}, {0: (o_nbr0, o_row0, o_mask0, o_ord0)}, {}, {}
+        for l in range(nl):
+            if l >= 1:
+                o_pair[l] = c2.take(27 * ns[l])
+                o_sub[l] = (c2.take(27 * npad[l]), c2.take(npad[l]), c2.take(npad[l] // 32),
+                            c2.take(npad[l] // 128) if tile_order else -1)
+            if l < depth:
+                o_dn[l] = (c2.take(8 * npad[l + 1]), c2.take(npad[l + 1]), c2.take(npad[l + 1] // 32))
+                o_up[l] = (c2.take(8 * npad[l]), c2.take(npad[l]), c2.take(npad[l] // 32))
+        buf2 = torch.empty((max(c2.off, 64),), dtype=torch.int32, device=dev)
+        b2 = buf2.data_ptr()
+        for l in range(nl):
+            v = L[l]
+            v.n = ns[l]
+            if l >= 1:
+                v.pair_subm = b2 + 4 * o_pair[l]
+                on, orow, om, oo = o_sub[l]
+                v.subm.nbr, v.subm.out_row, v.subm.tile_mask = b2 + 4 * on, b2 + 4 * orow, b2 + 4 * om
+                v.subm.tile_order = None if oo < 0 else b2 + 4 * oo
+            if l < depth:
+                on, orow, om = o_dn[l]
+                v.down.nbr, v.down.out_row, v.down.tile_mask = b2 + 4 * on, b2 + 4 * orow, b2 + 4 * om
+                on, orow, om = o_up[l]
+                v.up.nbr, v.up.out_row, v.up.tile_mask = b2 + 4 * on, b2 + 4 * orow, b2 + 4 * om
+        ws2 = _workspace(lib.m3d_levels_workspace_bytes(L, nl, int(batch_size)), dev)
+        rc = lib.m3d_levels_finish(L, nl, int(batch_size), _ptr(ws2), ws2.numel(), _stream())
+        _lib.check(rc, "m3d_levels_finish")
+        out = []
+        for l in range(nl):
+            n = ns[l]
+            d = dict(shape=shapes[l], n=n,
+                     indices=indices if l == 0 else buf[o_next[l - 1]:o_next[l - 1] + 4 * n].view(n, 4))
+            if l == 0:
+                d["pair_subm"] = buf[o_pair0:o_pair0 + 27 * n].view(27, n)
+                d["subm"] = ArenaSchedule(buf, o_nbr0, o_row0, o_mask0, o_ord0, n, npad[0], 27)
+            else:
+                d["pair_subm"] = buf2[o_pair[l]:o_pair[l] + 27 * n].view(27, n)
+                d["subm"] = ArenaSchedule(buf2, *o_sub[l], n, npad[l], 27)
+            if l < depth:
+                m_next = ns[l + 1]
+                d["pair_fwd"] = buf[o_pf[l]:o_pf[l] + 8 * n0].view(8, n0)[:, :m_next]
+                d["pair_bwd"] = buf[o_pb[l]:o_pb[l] + 8 * n0].view(8, n0)[:, :n]
+                d["next_indices"] = buf[o_next[l]:o_next[l] + 4 * m_next].view(m_next, 4)
+                d["next_shape"], d["n_next"] = shapes[l + 1], m_next
+                d["down"] = ArenaSchedule(buf2, *o_dn[l], -1, m_next, npad[l + 1], 8)
+                d["up"] = ArenaSchedule(buf2, *o_up[l], -1, n, npad[l], 8)
+            out.append(d)
+        return out
+
+    return finish
+
+
 def build_halo(sched, n_in, order_by_schedule=True):
     """Attach the halo of every 256-row tile to a schedule (m3d_build_halo): the distinct input rows the tile's
     pairs reference and, per pair, its index in that list.  conv_fwd then runs the halo kernel for split (sf32,

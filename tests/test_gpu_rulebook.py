@@ -185,3 +185,36 @@ def test_tile_order_is_heaviest_first_and_changes_no_result(device):
     a = ops.conv_fwd(x, w, plain, nv)
     b = ops.conv_fwd(x, w, sched, nv)
     assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("seeds,target", [([3], 30000), ([4, 5], 6000), ([6], 700)])
+def test_level_chain_in_two_calls_equals_level_by_level(device, seeds, target):
+    """m3d_levels_begin / m3d_levels_finish (all maps and schedules of a scene in two library calls, arrays carved
+    out of two buffers) against the level-by-level entry points: coordinates, kernel maps, schedules, tile masks and
+    launch orders equal bit for bit on every level."""
+    import bench
+    eng, _, _ = bench.build_engine(device, "bf16x6")
+    b = scenes.make_batch(seeds, target_voxels=target)
+    vox = ops.voxelize(torch.from_numpy(b["coord"]).to(device), torch.from_numpy(b["feat"]).to(device), b["offset"], 0.02)
+    assert eng.use_level_chain
+    got = eng.build_levels(vox["voxel_coords"], vox["spatial_shape"], vox["batch_size"])
+    eng.use_level_chain = False
+    ref = eng.build_levels(vox["voxel_coords"], vox["spatial_shape"], vox["batch_size"])
+    assert len(got) == len(ref) == 5
+    for l, (a, r) in enumerate(zip(got, ref)):
+        assert isinstance(a.subm, ops.ArenaSchedule) and not isinstance(r.subm, ops.ArenaSchedule)
+        assert a.n == r.n and list(a.shape) == list(r.shape) and a.n_next == r.n_next, l
+        assert torch.equal(a.indices, r.indices) and torch.equal(a.pair_subm, r.pair_subm), l
+        pairs = [(a.subm, r.subm)]
+        if r.down is not None:
+            assert torch.equal(a.pair_fwd, r.pair_fwd) and torch.equal(a.pair_bwd, r.pair_bwd), l
+            assert torch.equal(a.next_indices, r.next_indices) and list(a.next_shape) == list(r.next_shape), l
+            pairs += [(a.down, r.down), (a.up, r.up)]
+        else:
+            assert a.down is None and a.up is None and a.pair_fwd is None
+        for x, y in pairs:
+            assert (x.n, x.npad, x.k) == (y.n, y.npad, y.k), l
+            assert torch.equal(x.nbr, y.nbr) and torch.equal(x.out_row, y.out_row) and torch.equal(x.tile_mask, y.tile_mask), l
+            assert (x.tile_order is None) == (y.tile_order is None), l
+            if y.tile_order is not None:
+                assert torch.equal(x.tile_order, y.tile_order), l
