@@ -516,8 +516,14 @@ int m3d_net_run(const void* net, const m3d_net_maps_t* maps, const int64_t* leve
  *   m3d_levels_begin:  the chain of stride-2 maps (level l -> l + 1; the row count of a level stays on the device,
  *                      d_counts[l] = rows of level l + 1) and the submanifold map + schedule of level 0.  Only
  *                      levels[0].n is read; the per-row outputs of every level must hold levels[0].n rows.
- *   m3d_levels_finish: after the caller has read d_counts back and filled levels[l].n: submanifold maps + schedules
- *                      of levels >= 1 and the schedules of the strided maps and of their inverses. */
+ *                      `parts` selects M3D_LEVELS_CHAIN, M3D_LEVELS_FIRST or both: the two are independent of each
+ *                      other, a caller may enqueue them on two streams (each with a workspace of its own).
+ *   m3d_levels_finish: after the caller has read d_counts back and filled levels[l].n: for every level l in
+ *                      `level_mask` (bit l) the submanifold map + schedule of the level (l >= 1) and the schedules of
+ *                      its strided map into level l + 1 and of the inverse.  Levels are independent of each other
+ *                      here (level 0's part needs M3D_LEVELS_FIRST done): a caller may spread them over streams. */
+#define M3D_LEVELS_CHAIN 1
+#define M3D_LEVELS_FIRST 2
 typedef struct {
   const int32_t* indices;   /* [n][4]; level l + 1 reads next_indices of level l */
   int64_t n;                /* rows of the level */
@@ -532,9 +538,10 @@ typedef struct {
   /* subm: [27][npad(n)], [npad(n)], [npad(n)/32], [npad(n)/128] or NULL; down: [8][npad(n_next)] ...; up: [8][npad(n)] ... */
 } m3d_level_t;
 size_t m3d_levels_workspace_bytes(const m3d_level_t* levels, int n_levels, int batch_size);
-int m3d_levels_begin(const m3d_level_t* levels, int n_levels, int batch_size, int64_t* d_counts, void* d_ws, size_t ws_bytes,
-                     void* stream);
-int m3d_levels_finish(const m3d_level_t* levels, int n_levels, int batch_size, void* d_ws, size_t ws_bytes, void* stream);
+int m3d_levels_begin(const m3d_level_t* levels, int n_levels, int batch_size, int parts, int64_t* d_counts, void* d_ws,
+                     size_t ws_bytes, void* stream);
+int m3d_levels_finish(const m3d_level_t* levels, int n_levels, int batch_size, unsigned level_mask, void* d_ws,
+                      size_t ws_bytes, void* stream);
 
 #ifdef __cplusplus
 }

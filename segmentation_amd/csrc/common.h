@@ -110,7 +110,7 @@ size_t sort_pairs_ws_bytes(int64_t nmax);
 size_t unique_ws_bytes(int64_t nmax);
 
 // Stable LSD radix sort of (key, value) pairs, ascending by key bits [0, nbits).
-// The element count is read from *d_count on the device (<= nmax).  On return the sorted
+// The element count is read from *d_count on the device (<= nmax); d_count == nullptr: all nmax elements.  On return the sorted
 // pairs are in (d_keys, d_vals); (d_keys_alt, d_vals_alt) are clobbered.
 // With result_in_alt != nullptr the pass count is not rounded up to an even number: *result_in_alt says
 // whether the sorted pairs ended in the alt buffers (odd pass count) or in (d_keys, d_vals).

@@ -47,18 +47,19 @@ static int subm_of_level(const m3d_level_t& v, int batch_size, void* ws, size_t 
   return M3D_OK;
 }
 
-extern "C" int m3d_levels_begin(const m3d_level_t* L, int n_levels, int batch_size, int64_t* d_counts, void* d_ws,
-                                size_t ws_bytes, void* stream) {
+extern "C" int m3d_levels_begin(const m3d_level_t* L, int n_levels, int batch_size, int parts, int64_t* d_counts,
+                                void* d_ws, size_t ws_bytes, void* stream) {
   const char* who = "m3d_levels_begin";
   M3D_CHECK_ARG(L && n_levels >= 1 && n_levels <= 16 && L[0].n > 0, "%s: bad arguments", who);
-  M3D_CHECK_ARG(n_levels == 1 || d_counts, "%s: d_counts missing", who);
+  M3D_CHECK_ARG(parts >= 1 && parts <= 3, "%s: parts must be M3D_LEVELS_CHAIN, M3D_LEVELS_FIRST or both", who);
+  M3D_CHECK_ARG(n_levels == 1 || d_counts || !(parts & M3D_LEVELS_CHAIN), "%s: d_counts missing", who);
   const size_t need = levels_ws_need(L, n_levels, batch_size, true);
   if (d_ws == nullptr || ws_bytes < need) {
     set_error("%s: workspace too small (%zu given, %zu needed)", who, ws_bytes, need);
     return M3D_ENOSPC;
   }
   // the chain of strided maps: the row count of a level stays on the device and feeds the next one
-  for (int l = 0; l + 1 < n_levels; ++l) {
+  for (int l = 0; (parts & M3D_LEVELS_CHAIN) && l + 1 < n_levels; ++l) {
     M3D_CHECK_ARG(L[l].indices && L[l].next_indices && L[l].pair_fwd && L[l].pair_bwd && L[l].ld == L[0].n,
                   "%s: level %d: strided-map outputs missing or column stride != rows of level 0", who, l);
     M3D_CHECK_ARG(L[l + 1].indices == L[l].next_indices, "%s: level %d does not read the outputs of level %d", who, l + 1, l);
@@ -67,11 +68,12 @@ extern "C" int m3d_levels_begin(const m3d_level_t* L, int n_levels, int batch_si
       return rc;
   }
   // level 0 needs nothing from the chain: its map and schedule keep the GPU busy while the counts travel
-  return subm_of_level(L[0], batch_size, d_ws, ws_bytes, stream);
+  if (parts & M3D_LEVELS_FIRST) return subm_of_level(L[0], batch_size, d_ws, ws_bytes, stream);
+  return M3D_OK;
 }
 
-extern "C" int m3d_levels_finish(const m3d_level_t* L, int n_levels, int batch_size, void* d_ws, size_t ws_bytes,
-                                 void* stream) {
+extern "C" int m3d_levels_finish(const m3d_level_t* L, int n_levels, int batch_size, unsigned level_mask, void* d_ws,
+                                 size_t ws_bytes, void* stream) {
   const char* who = "m3d_levels_finish";
   M3D_CHECK_ARG(L && n_levels >= 1 && n_levels <= 16, "%s: bad arguments", who);
   for (int l = 0; l < n_levels; ++l) M3D_CHECK_ARG(L[l].n > 0, "%s: level %d has no rows", who, l);
@@ -81,6 +83,7 @@ extern "C" int m3d_levels_finish(const m3d_level_t* L, int n_levels, int batch_s
     return M3D_ENOSPC;
   }
   for (int l = 0; l < n_levels; ++l) {
+    if (!((level_mask >> l) & 1u)) continue;
     if (l >= 1)
       if (int rc = subm_of_level(L[l], batch_size, d_ws, ws_bytes, stream)) return rc;
     if (l + 1 < n_levels) {

@@ -26,7 +26,7 @@ constexpr int kSortBlock = 256;    // 4 waves per workgroup
 constexpr int kRounds = kWaveItems / 64;
 
 __global__ __launch_bounds__(kSortBlock) void radix_hist_kernel(
-    const uint64_t* __restrict__ keys, const int* __restrict__ d_count, int shift,
+    const uint64_t* __restrict__ keys, const int* __restrict__ d_count, int host_count, int shift,
     uint32_t* __restrict__ counts, int nchunks) {
   __shared__ uint32_t h[kSortBlock / 64][256];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -34,7 +34,7 @@ __global__ __launch_bounds__(kSortBlock) void radix_hist_kernel(
   for (int i = lane; i < 256; i += 64) h[wave][i] = 0;
   __syncthreads();
   if (chunk < nchunks) {
-    const int64_t m = *d_count;
+    const int64_t m = d_count ? *d_count : host_count;
     const int64_t base = (int64_t)chunk * kWaveItems;
     uint64_t kr[kRounds];
 #pragma unroll
@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void radix_scan_kernel(uint32_t* __restrict__ 
 
 __global__ __launch_bounds__(kSortBlock) void radix_scatter_kernel(
     const uint64_t* __restrict__ kin, const uint32_t* __restrict__ vin,
-    uint64_t* __restrict__ kout, uint32_t* __restrict__ vout, const int* __restrict__ d_count,
+    uint64_t* __restrict__ kout, uint32_t* __restrict__ vout, const int* __restrict__ d_count, int host_count,
     int shift, const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ totals,
     int nchunks) {
   __shared__ uint32_t run_s[kSortBlock / 64][256];
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(kSortBlock) void radix_scatter_kernel(
   uint32_t offs[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) offs[q] = chunk < nchunks ? offsets[(int64_t)(q * 64 + lane) * nchunks + chunk] : 0u;
-  const int64_t m = chunk < nchunks ? (int64_t)*d_count : 0;
+  const int64_t m = chunk < nchunks ? (int64_t)(d_count ? *d_count : host_count) : 0;
   const int64_t base = (int64_t)chunk * kWaveItems;
   // all of the wave's elements are requested up front: the rounds below are serialised by the running offsets
   // in LDS, and a load issued inside a round would add its full latency to every one of them
@@ -170,12 +170,12 @@ constexpr int kSmallSortRounds = 4;
 constexpr int kSmallSortMax = kSmallSortWaves * kSmallSortRounds * 64;  // 4096: longer arrays are faster on many CUs
 
 __global__ __launch_bounds__(kSmallSortWaves * 64) void radix_sort_small_kernel(
-    uint64_t* k0, uint32_t* v0, uint64_t* k1, uint32_t* v1, const int* __restrict__ d_count, int passes) {
+    uint64_t* k0, uint32_t* v0, uint64_t* k1, uint32_t* v1, const int* __restrict__ d_count, int host_count, int passes) {
   __shared__ uint32_t cnt_s[kSmallSortWaves][256];
   __shared__ uint32_t base_s[256];
   __shared__ uint32_t wsum[4];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int m = *d_count;
+  const int m = d_count ? *d_count : host_count;
   const int rounds = (m + kSmallSortWaves * 64 - 1) / (kSmallSortWaves * 64);  // per wave, <= kSmallSortRounds
   const int first = wave * rounds * 64;
   const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
@@ -283,7 +283,7 @@ int sort_pairs(uint64_t* d_keys, uint32_t* d_vals, uint64_t* d_keys_alt, uint32_
   else if (passes & 1) ++passes;  // an even number of passes leaves the result in (d_keys, d_vals)
   if (nmax <= kSmallSortMax) {
     hipLaunchKernelGGL(radix_sort_small_kernel, dim3(1), dim3(kSmallSortWaves * 64), 0, stream, d_keys, d_vals,
-                       d_keys_alt, d_vals_alt, d_count, passes);
+                       d_keys_alt, d_vals_alt, d_count, (int)nmax, passes);
     M3D_LAUNCH_CHECK();
     return M3D_OK;
   }
@@ -294,11 +294,11 @@ int sort_pairs(uint64_t* d_keys, uint32_t* d_vals, uint64_t* d_keys_alt, uint32_
   uint32_t* vo = d_vals_alt;
   for (int p = 0; p < passes; ++p) {
     const int shift = 8 * p;
-    hipLaunchKernelGGL(radix_hist_kernel, dim3(nblocks), dim3(kSortBlock), 0, stream, ki, d_count,
+    hipLaunchKernelGGL(radix_hist_kernel, dim3(nblocks), dim3(kSortBlock), 0, stream, ki, d_count, (int)nmax,
                        shift, counts, nchunks);
     hipLaunchKernelGGL(radix_scan_kernel, dim3(256), dim3(256), 0, stream, counts, totals, nchunks);
     hipLaunchKernelGGL(radix_scatter_kernel, dim3(nblocks), dim3(kSortBlock), 0, stream, ki, vi,
-                       ko, vo, d_count, shift, counts, totals, nchunks);
+                       ko, vo, d_count, (int)nmax, shift, counts, totals, nchunks);
     uint64_t* tk = ki; ki = ko; ko = tk;
     uint32_t* tv = vi; vi = vo; vo = tv;
   }

@@ -20,10 +20,6 @@ __device__ inline uint64_t lin_key(int b, int x, int y, int z, const Shape3& sh)
              (uint64_t)sh.s[2] + (uint64_t)z;
 }
 
-__global__ void set_int_kernel(int* p, int v) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) *p = v;
-}
-
 // ------------------------------------------------------------------------------ SubM k3
 __global__ void subm_insert_kernel(const int4* __restrict__ idx, int64_t n, Shape3 sh,
                                    uint64_t* __restrict__ tkeys, int32_t* __restrict__ tvals,
@@ -737,7 +733,6 @@ extern "C" int m3d_build_schedule(const int32_t* d_pair, int k, int64_t ld, int6
       }
       nbits = 3 * mb + bits_for((uint64_t)(batch_size > 1 ? batch_size - 1 : 1));
     }
-    hipLaunchKernelGGL(set_int_kernel, dim3(1), dim3(64), 0, stream, count, (int)n);
     if (mode == 3) {
       const int cs = cell_shift ? (cell_shift > 15 ? 15 : cell_shift) : 6;
       const int cb = mb > cs ? mb - cs : 0;  // bits per axis of the cell coordinate
@@ -751,7 +746,8 @@ extern "C" int m3d_build_schedule(const int32_t* d_pair, int k, int64_t ld, int6
     }
     M3D_LAUNCH_CHECK();
     bool in_alt = false;
-    int rc = sort_pairs(keys, vals, kalt, valt, count, n, nbits, sws, sb, stream, &in_alt);
+    (void)count;  // every row takes part: the count is the host's n
+    int rc = sort_pairs(keys, vals, kalt, valt, nullptr, n, nbits, sws, sb, stream, &in_alt);
     if (rc != M3D_OK) return rc;
     order = in_alt ? valt : vals;
   }

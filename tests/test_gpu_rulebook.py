@@ -197,11 +197,21 @@ def test_level_chain_in_two_calls_equals_level_by_level(device, seeds, target):
     b = scenes.make_batch(seeds, target_voxels=target)
     vox = ops.voxelize(torch.from_numpy(b["coord"]).to(device), torch.from_numpy(b["feat"]).to(device), b["offset"], 0.02)
     assert eng.use_level_chain
-    got = eng.build_levels(vox["voxel_coords"], vox["spatial_shape"], vox["batch_size"])
+    got_one = eng.build_levels(vox["voxel_coords"], vox["spatial_shape"], vox["batch_size"])
+    # the independent parts of the two calls spread over three more streams (`parts` / `level_mask` of the entry points)
+    aux = [torch.cuda.Stream(device=device) for _ in range(3)]
+    modes = [eng.sched_modes[min(l, len(eng.sched_modes) - 1)] for l in range(5)]
+    dicts = ops.level_chain_begin(vox["voxel_coords"], vox["spatial_shape"], vox["batch_size"], 4, modes, True,
+                                  aux_streams=aux)()
+    got_streams = [type("L", (), dict(d, down=d.get("down"), up=d.get("up"), pair_fwd=d.get("pair_fwd"),
+                                      pair_bwd=d.get("pair_bwd"), next_indices=d.get("next_indices"),
+                                      next_shape=d.get("next_shape"), n_next=d.get("n_next", 0)))() for d in dicts]
     eng.use_level_chain = False
     ref = eng.build_levels(vox["voxel_coords"], vox["spatial_shape"], vox["batch_size"])
-    assert len(got) == len(ref) == 5
-    for l, (a, r) in enumerate(zip(got, ref)):
+    torch.cuda.synchronize()
+    assert len(got_streams) == len(got_one) == len(ref) == 5
+    for l, (a, r) in enumerate(list(zip(got_streams, ref)) + list(zip(got_one, ref))):
+        l %= 5
         assert isinstance(a.subm, ops.ArenaSchedule) and not isinstance(r.subm, ops.ArenaSchedule)
         assert a.n == r.n and list(a.shape) == list(r.shape) and a.n_next == r.n_next, l
         assert torch.equal(a.indices, r.indices) and torch.equal(a.pair_subm, r.pair_subm), l
