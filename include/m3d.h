@@ -439,6 +439,20 @@ int m3d_head_fused_terms(const void* d_in_split, int cin, int64_t n, int terms, 
                          float* d_logits, int64_t ldl, int32_t* d_voxel_label, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * The two torch_scatter operators the reference's model and loss code call, on [rows, c] f32 tensors.
+ * m3d_segment_csr replaces torch_scatter.segment_csr(src, indptr, reduce="mean" | "sum")
+ * (mosaic3d/src/models/losses/caption_loss.py:223): out[s] = sum (mean = 0) or mean (mean = 1) of
+ * src[indptr[s] : indptr[s + 1]], zero for an empty segment; rows are summed in a fixed order.
+ * m3d_scatter_rows replaces torch_scatter.scatter(src, index, dim=0, out=..., reduce="mean" | "sum")
+ * (mosaic3d/src/models/utils/structure.py:58, spconv_unet_v1m3_pdnorm.py:410): d_out [n_out, c] is added to
+ * (callers start from zeros, or from `out`), out[index[i]] += src[i] with float atomics; with mean = 1 every row that
+ * received k > 1 rows is divided by k afterwards (d_count [n_out] i32 is scratch, required for a mean). */
+int m3d_segment_csr(const float* d_src, int c, const int64_t* d_indptr, int64_t n_segments, int mean, float* d_out,
+                    void* stream);
+int m3d_scatter_rows(const float* d_src, const int64_t* d_index, int64_t n, int c, int64_t n_out, int mean, float* d_out,
+                     int32_t* d_count, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * A whole network enqueued by one call.  Replaces the layer-by-layer walk of SpUNetBase.forward
  * (mosaic3d/src/models/networks/spunet/spconv_unet_v1m3_pdnorm.py:380-414: conv_input, the encoder stages, the decoder
  * stages with their skip concatenations, final) and of the head (clip_alignment_loss.py:138-147,

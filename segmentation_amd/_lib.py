@@ -79,6 +79,8 @@ SIGNATURES = {
     "m3d_net_destroy": (None, [_vp]),
     "m3d_net_arena_bytes": (_sz, [_vp, ctypes.POINTER(_i64)]),
     "m3d_net_run": (_int, [_vp, _vp, ctypes.POINTER(_i64), _vp, _vp, _sz, _vp, _i64, _vp, _vp, _vp, _i64, _vp]),
+    "m3d_segment_csr": (_int, [_vp, _int, _vp, _i64, _int, _vp, _vp]),
+    "m3d_scatter_rows": (_int, [_vp, _vp, _i64, _int, _i64, _int, _vp, _vp, _vp]),
     "m3d_levels_workspace_bytes": (_sz, [_vp, _int, _int]),
     "m3d_levels_begin": (_int, [_vp, _int, _int, _int, _vp, _vp, _sz, _vp]),
     "m3d_levels_finish": (_int, [_vp, _int, _int, ctypes.c_uint, _vp, _sz, _vp]),

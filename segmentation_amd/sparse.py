@@ -413,12 +413,74 @@ class SparseSequential(SparseModule):
 
 
 # ----------------------------------------------------------------------------- torch_scatter subset
+def _on_kernels(src):
+    """[rows, c] f32 on the GPU goes to the HIP kernels (m3d_scatter_rows / m3d_segment_csr); anything else (CPU
+    tensors of the reference's own CPU code paths and of the CPU tests, other ranks and dtypes) to torch operators."""
+    return src.is_cuda and src.dtype == torch.float32 and src.dim() == 2
+
+
+class _ScatterFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, src, index, n_out, mean, out0):
+        from . import _lib, ops
+        lib = _lib.load()
+        src = src.contiguous()
+        index = index.contiguous().long()
+        ops._need_cuda(src, index)
+        out = torch.zeros((n_out, src.shape[1]), dtype=torch.float32, device=src.device) if out0 is None else out0
+        count = torch.empty((n_out,), dtype=torch.int32, device=src.device) if mean else None
+        _lib.check(lib.m3d_scatter_rows(ops._ptr(src), ops._ptr(index), src.shape[0], src.shape[1], n_out, int(mean),
+                                        ops._ptr(out), ops._ptr(count), ops._stream()), "m3d_scatter_rows")
+        ctx.save_for_backward(index, count)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        index, count = ctx.saved_tensors
+        gs = g[index]
+        if count is not None:
+            gs = gs / count.clamp(min=1)[index].to(g.dtype).unsqueeze(1)
+        return gs, None, None, None, None
+
+
+class _SegmentCsrFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, src, indptr, mean):
+        from . import _lib, ops
+        lib = _lib.load()
+        src = src.contiguous()
+        indptr = indptr.to(src.device).contiguous().long()
+        ops._need_cuda(src, indptr)
+        n_seg = indptr.numel() - 1
+        out = torch.empty((n_seg, src.shape[1]), dtype=torch.float32, device=src.device)
+        _lib.check(lib.m3d_segment_csr(ops._ptr(src), src.shape[1], ops._ptr(indptr), n_seg, int(mean), ops._ptr(out),
+                                       ops._stream()), "m3d_segment_csr")
+        ctx.save_for_backward(indptr)
+        ctx.mean, ctx.rows = mean, src.shape[0]
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (indptr,) = ctx.saved_tensors
+        counts = indptr[1:] - indptr[:-1]
+        if ctx.mean:
+            g = g / counts.clamp(min=1).to(g.dtype).unsqueeze(1)
+        seg = torch.repeat_interleave(torch.arange(counts.numel(), device=g.device), counts)
+        gs = torch.zeros((ctx.rows, g.shape[1]), dtype=g.dtype, device=g.device)
+        lo, hi = int(indptr[0]), int(indptr[-1])
+        gs[lo:hi] = g[seg]
+        return gs, None, None
+
+
 def scatter(src, index, dim=0, out=None, dim_size=None, reduce="sum"):
     """torch_scatter.scatter for reduce in {sum, mean} along dim 0 (structure.py:58, v1m3:410)."""
     if dim != 0:
         raise NotImplementedError("scatter: only dim=0 is implemented")
     if reduce not in ("sum", "add", "mean"):
         raise NotImplementedError(f"scatter: reduce={reduce!r} is not implemented")
+    if _on_kernels(src) and (out is None or (out.is_contiguous() and out.dtype == torch.float32)):
+        n = out.shape[0] if out is not None else (int(index.max()) + 1 if dim_size is None else dim_size)
+        return _ScatterFn.apply(src, index, n, reduce == "mean", out)
     n = int(index.max()) + 1 if dim_size is None else dim_size
     if out is None:
         out = torch.zeros((n,) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
@@ -433,6 +495,8 @@ def segment_csr(src, indptr, out=None, reduce="sum"):
     """torch_scatter.segment_csr for reduce in {sum, mean} (caption_loss.py:223)."""
     if reduce not in ("sum", "add", "mean"):
         raise NotImplementedError(f"segment_csr: reduce={reduce!r} is not implemented")
+    if _on_kernels(src) and out is None:
+        return _SegmentCsrFn.apply(src, indptr, reduce == "mean")
     counts = indptr[1:] - indptr[:-1]
     seg = torch.repeat_interleave(torch.arange(counts.numel(), device=src.device), counts)
     res = torch.zeros((counts.numel(),) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
