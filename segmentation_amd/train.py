@@ -82,9 +82,25 @@ def caption_loss(point_features, text_features, labels_per_segment, point_indice
     device = point_features.device
     if normalize:
         point_features = F.normalize(point_features, dim=-1)
-    logits = point_features @ text_features.T.to(device)
+    text, col_mask = _pad_text_rows(text_features.to(device))
+    logits = point_features @ text.T
     return _loss_from_logits(logits, labels_per_segment, point_indices, caption_offsets, num_points_per_caption,
-                             logit_scale, reduction, row_map)
+                             logit_scale, reduction, row_map, col_mask)
+
+
+def _pad_text_rows(text):
+    """On the GPU the number of distinct text rows U becomes the row length of the [N, U] logits and a GEMM dimension;
+    an odd U (511 as readily as 512: it is whatever np.unique leaves) puts every row of the logits off the 16-byte
+    grid and the vendor GEMM and softmax kernels on their slow paths (measured: 26 instead of 20 ms of backward at
+    U = 511).  U is padded to a multiple of 32 with zero rows; their logits are set to -inf by the returned mask, so
+    they add exp(-inf) = 0 to the softmax sums and receive no gradient: same loss, same gradients."""
+    u = text.shape[0]
+    if not text.is_cuda or u % 32 == 0:
+        return text, None
+    pad = (-u) % 32
+    mask = torch.zeros(u + pad, dtype=text.dtype, device=text.device)
+    mask[u:] = float("-inf")
+    return torch.cat([text, text.new_zeros((pad, text.shape[1]))], 0), mask
 
 
 class _TallMatmul(torch.autograd.Function):
@@ -129,7 +145,7 @@ def caption_loss_folded(pre_features, weight, bias, text_features, labels_per_se
     become [N, C_in]-sized work; autograd carries the gradient to weight and bias through the small matrices."""
     device = pre_features.device
     w = weight.reshape(weight.shape[0], -1)  # [D, C_in]
-    text = text_features.to(device)
+    text, col_mask = _pad_text_rows(text_features.to(device))
     pre_features = pre_features.contiguous()
     logits = _TallMatmul.apply(pre_features, w.T @ text.T)
     if bias is not None:
@@ -145,14 +161,16 @@ def caption_loss_folded(pre_features, weight, bias, text_features, labels_per_se
         # F.normalize: x / max(|x|, 1e-12)
         logits = logits * (1.0 / sq.clamp_min(0.0).sqrt().clamp_min(1e-12))[:, None]
     return _loss_from_logits(logits, labels_per_segment, point_indices, caption_offsets, num_points_per_caption,
-                             logit_scale, reduction, row_map)
+                             logit_scale, reduction, row_map, col_mask)
 
 
 def _loss_from_logits(logits, labels_per_segment, point_indices, caption_offsets, num_points_per_caption, logit_scale,
-                      reduction, row_map):
+                      reduction, row_map, col_mask=None):
     device = logits.device
     if logit_scale is not None:
         logits = logit_scale.exp() * logits
+    if col_mask is not None:   # padding columns of _pad_text_rows: out of the softmax
+        logits = logits + col_mask
     scores = F.log_softmax(logits, dim=-1)
     # The reference gathers scores[point_indices] ([L, U]), averages it per caption and lets nll_loss pick the
     # caption's own column.  Only that column is ever read, so the same number comes from one scalar per
