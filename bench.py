@@ -316,11 +316,11 @@ def main():
 
     elapsed, nvox_all = sharding.reduce_job(elapsed, float(nvox), dist, device)
     # every rank measured the convolution launches of its own scenes on its own GPU: min / median / max over the ranks
-    conv_secs = sum(e0.elapsed_time(e1) * 1e-3 for kind, _, e0, e1, _, _ in prof if kind in ("igemm", "dma", "halo"))
+    conv_secs = sum(e0.elapsed_time(e1) * 1e-3 for kind, _, e0, e1, _, _ in prof if kind in ("igemm", "dma"))
     conv_rank_ms = sharding.reduce_stats(conv_secs / psteps / max(len(my), 1) * 1e3, dist, device)
 
     if rank == 0:
-        ig = [(f, e0.elapsed_time(e1) * 1e-3, b) for kind, f, e0, e1, _, b in prof if kind in ("igemm", "dma", "halo")]
+        ig = [(f, e0.elapsed_time(e1) * 1e-3, b) for kind, f, e0, e1, _, b in prof if kind in ("igemm", "dma")]
         flops = sum(f for f, _, _ in ig)
         secs = sum(t for _, t, _ in ig)
         alg_bytes = sum(b for _, _, b in ig)

@@ -10,7 +10,8 @@
  *   - every pointer named d_* is DEVICE memory owned by the caller (PyTorch tensors in practice);
  *     the library never allocates or frees device memory; its only state is a thread-local error string,
  *     the per-device scratch of m3d_bn_stats_static and the per-device f16 status word (m3d_f16_status);
- *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it, nothing synchronises;
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it and nothing synchronises, with one
+ *     exception: m3d_f16_status waits for `stream` before it reads the status word back;
  *   - data-dependent output sizes (number of voxels) are written to device memory; outputs are
  *     sized by the caller for the worst case (one row per input row);
  *   - return value: 0 on success, negative M3D_E* code on failure; m3d_last_error() gives text;
@@ -258,8 +259,7 @@ int m3d_conv_fwd_f32(const float* d_in0, int c0, const float* d_in1, int c1,
 int m3d_conv_fwd_sf32(const void* d_in0, int c0, int64_t rows0, const void* d_in1, int c1,
                       int64_t rows1, const void* d_weight, int k, int cout, const int32_t* d_nbr,
                       const int32_t* d_out_row, const uint32_t* d_tile_mask, int64_t n, int64_t npad, const int32_t* d_tile_order,
-                      const int32_t* d_halo_cnt, const int32_t* d_halo_rows, const uint16_t* d_halo_loc,
-                      const int32_t* d_halo_order, const float* d_scale, const float* d_shift, const float* d_residual, int relu,
+                      const float* d_scale, const float* d_shift, const float* d_residual, int relu,
                       float* d_out, int64_t ldo, void* d_out_split, int terms, void* d_ws,
                       size_t ws_bytes, void* stream);
 
@@ -339,23 +339,6 @@ int m3d_bn_act_backward(const float* d_x, const float* d_dy, const float* d_y, i
 size_t m3d_bn_stats_static_max_bytes(void);
 int m3d_bn_stats_static(const float* d_x, int64_t n, int c, float* d_mean, float* d_var, void* stream);
 
-/* Halo of a tile schedule (optional accelerator of m3d_conv_fwd_sf32 with terms = 2, meant for 3x3x3
- * submanifold maps of large levels).  For every tile of m3d_halo_tile_rows() = 256 schedule rows: the
- * distinct input rows its pairs reference (at most m3d_halo_cap() = 640; a tile with more is marked -1
- * and convolved offset by offset) and, per pair, the index of its input row in that list.  With a halo
- * the convolution loads each distinct input row once per 32-channel slab instead of once per kernel offset.
- *   d_nbr [k,npad], d_out_row [npad]: from m3d_build_schedule (npad is a multiple of 256)
- *   order_by_schedule != 0 (submanifold maps: input rows = output rows; needs n_in = rows and a
- *     workspace of n_in * 4 bytes): halo rows are listed in schedule order, which keeps the LDS reads of
- *     neighbouring rows on distinct banks; 0: listed by row index
- *   d_halo_cnt [npad/256] i32, d_halo_rows [npad/256, 640] i32, d_halo_loc [npad/256, k, 256] u16,
- *   d_halo_order [npad/256] i32: the order in which the convolution grid takes the tiles (-1 tiles first)
- * No counterpart in the reference. */
-int m3d_halo_cap(void);
-int m3d_halo_tile_rows(void);
-int m3d_build_halo(const int32_t* d_nbr, const int32_t* d_out_row, int k, int64_t npad, int64_t n_in,
-                   int order_by_schedule, int32_t* d_halo_cnt, int32_t* d_halo_rows, uint16_t* d_halo_loc,
-                   int32_t* d_halo_order, void* d_ws, size_t ws_bytes, void* stream);
 /* `terms` of the split-format entry points is 1, 2, 3 (bf16 terms) or M3D_FMT_F16_PAIR: [rows + 1][C/32][2][32] f16,
  * term 0 = f16(x), term 1 = f16((x - term 0) * 2^11).
  * m3d_f16_status: every kernel that writes the pair format sets a per-device status word when a value lies beyond
@@ -529,7 +512,9 @@ int m3d_net_run(const void* net, const m3d_net_maps_t* maps, const int64_t* leve
  * (same bits).
  *   m3d_levels_begin:  the chain of stride-2 maps (level l -> l + 1; the row count of a level stays on the device,
  *                      d_counts[l] = rows of level l + 1) and the submanifold map + schedule of level 0.  Only
- *                      levels[0].n is read; the per-row outputs of every level must hold levels[0].n rows.
+ *                      levels[0].n is read; level l is processed for levels[l].ld rows at most, where ld must be a
+ *                      bound of the level's rows: min(levels[0].n, batch_size * cells of the level's grid) or more,
+ *                      levels[0].n at most; next_indices of level l holds ld of level l + 1 rows.
  *                      `parts` selects M3D_LEVELS_CHAIN, M3D_LEVELS_FIRST or both: the two are independent of each
  *                      other, a caller may enqueue them on two streams (each with a workspace of its own).
  *   m3d_levels_finish: after the caller has read d_counts back and filled levels[l].n: for every level l in
@@ -542,10 +527,10 @@ typedef struct {
   const int32_t* indices;   /* [n][4]; level l + 1 reads next_indices of level l */
   int64_t n;                /* rows of the level */
   int64_t shape[3];         /* spatial shape of the level */
-  int32_t* next_indices;    /* [levels[0].n][4] coordinates of the next coarser level (unused on the last level) */
+  int32_t* next_indices;    /* [bound of level l + 1][4] coordinates of the next coarser level (unused on the last level) */
   int32_t* pair_fwd;        /* [8][ld] */
   int32_t* pair_bwd;        /* [8][ld] */
-  int64_t ld;               /* column stride of pair_fwd / pair_bwd = levels[0].n */
+  int64_t ld;               /* column stride of pair_fwd / pair_bwd = the bound of the level's rows (see above) */
   int32_t* pair_subm;       /* [27][n] */
   int32_t subm_mode;        /* m3d_build_schedule mode of the submanifold schedule */
   struct { int32_t* nbr; int32_t* out_row; uint32_t* tile_mask; int32_t* tile_order; } subm, down, up;

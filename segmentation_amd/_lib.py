@@ -45,7 +45,7 @@ SIGNATURES = {
                                 _vp, _vp, _vp, _int, _vp, _i64, _vp, _int, _int, _vp, _sz, _vp]),
     "m3d_schedule_tile_order": (_int, [_vp, _i64, _vp, _vp]),
     "m3d_conv_fwd_sf32": (_int, [_vp, _int, _i64, _vp, _int, _i64, _vp, _int, _int, _vp, _vp, _vp, _i64, _i64, _vp,
-                                 _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _vp, _i64, _vp, _int, _vp, _sz, _vp]),
+                                 _vp, _vp, _vp, _int, _vp, _i64, _vp, _int, _vp, _sz, _vp]),
     "m3d_conv_bwd_weight_workspace_bytes": (_sz, [_i64, _int, _int, _int]),
     "m3d_conv_bwd_weight_f32": (_int, [_vp, _int, _vp, _int, _int, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _sz, _vp]),
     "m3d_conv_bwd_weight_bf16x3": (_int, [_vp, _int, _vp, _int, _int, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _sz, _vp]),
@@ -58,9 +58,6 @@ SIGNATURES = {
     "m3d_bn_stats_static_max_bytes": (_sz, []),
     "m3d_bn_stats_static": (_int, [_vp, _i64, _int, _vp, _vp, _vp]),
     "m3d_bn_backward_reduce": (_int, [_vp, _vp, _vp, _i64, _int, _vp, _vp, _vp, _sz, _vp]),
-    "m3d_halo_cap": (_int, []),
-    "m3d_halo_tile_rows": (_int, []),
-    "m3d_build_halo": (_int, [_vp, _vp, _int, _i64, _i64, _int, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "m3d_sf32_bytes": (_sz, [_i64, _int, _int]),
     "m3d_split_f32": (_int, [_vp, _i64, _int, _int, _vp, _vp]),
     "m3d_conv_packed_weight_bytes": (_sz, [_int, _int, _int, _int]),

@@ -1162,9 +1162,6 @@ static ConvPlan plan_conv(int64_t npad, int cout, int kvol, int cin) {
   return plan_for_tile(32, bn, 1);
 }
 
-int run_conv_halo(const ConvArgs& a, const int32_t* d_cnt, const int32_t* d_rows, const uint16_t* d_loc,
-                  const int32_t* d_order, hipStream_t stream);  // conv_halo.hip
-
 }  // namespace m3d
 
 using namespace m3d;
@@ -1344,8 +1341,7 @@ extern "C" int m3d_conv_fwd_sf32(const void* d_in0, int c0, int64_t rows0, const
                                  int64_t rows1, const void* d_weight, int k, int cout,
                                  const int32_t* d_nbr, const int32_t* d_out_row,
                                  const uint32_t* d_tile_mask, int64_t n, int64_t npad, const int32_t* d_tile_order,
-                                 const int32_t* d_halo_cnt, const int32_t* d_halo_rows, const uint16_t* d_halo_loc,
-                                 const int32_t* d_halo_order, const float* d_scale, const float* d_shift, const float* d_residual,
+                                 const float* d_scale, const float* d_shift, const float* d_residual,
                                  int relu, float* d_out, int64_t ldo, void* d_out_split, int terms,
                                  void* d_ws, size_t ws_bytes, void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
@@ -1376,12 +1372,6 @@ extern "C" int m3d_conv_fwd_sf32(const void* d_in0, int c0, int64_t rows0, const
   a.out = d_out; a.n = n; a.npad = npad; a.ldo = ldo; a.c0 = c0; a.c1 = c1;
   a.cout = cout; a.kvol = k; a.relu = relu;
   a.out_split = static_cast<char*>(d_out_split); a.terms = terms;
-  if (d_halo_cnt != nullptr) {
-    M3D_CHECK_ARG(d_halo_rows && d_halo_loc && d_halo_order && d_nbr, "%s: incomplete halo", who);
-    M3D_CHECK_ARG(terms == 2 && npad % m3d_halo_tile_rows() == 0, "%s: the halo kernel needs terms == 2 and npad %% %d == 0",
-                  who, m3d_halo_tile_rows());
-    return run_conv_halo(a, d_halo_cnt, d_halo_rows, d_halo_loc, d_halo_order, stream);
-  }
   a.tile_order = d_tile_order;
   if (int rc = device_symbols(&a.zbuf, &a.f16_status)) return rc;
   return run_conv(a, terms == 2 ? 3 : (terms == 3 ? 4 : (terms == kFmtF16 ? 9 : 6)), true, d_ws, ws_bytes, stream, who);

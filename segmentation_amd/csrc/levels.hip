@@ -9,10 +9,19 @@
 
 using namespace m3d;
 
+// Upper bound of the rows of level l before the counts are known: no more than level 0 has, and no more than the
+// level's grid has cells.
+static int64_t level_bound(const m3d_level_t* L, int l, int batch_size) {
+  const int64_t n0 = L[0].n;
+  if (l == 0 || batch_size <= 0) return n0;
+  const int64_t cells = (int64_t)batch_size * L[l].shape[0] * L[l].shape[1] * L[l].shape[2];
+  return std::max<int64_t>(1, std::min(n0, cells));
+}
+
 static size_t levels_ws_need(const m3d_level_t* L, int n_levels, int batch_size, bool begin) {
   size_t need = 256;
   for (int l = 0; l < n_levels; ++l) {
-    const int64_t n = begin ? L[0].n : L[l].n;  // the chain is sized by the bound of its first level
+    const int64_t n = begin ? level_bound(L, l, batch_size) : L[l].n;
     if (begin && l + 1 < n_levels) need = std::max(need, m3d_strided_rulebook_workspace_bytes(n, L[l].shape, batch_size));
     if (begin ? l == 0 : l >= 1) {
       need = std::max(need, m3d_subm_rulebook_workspace_bytes(L[l].n, L[l].shape, batch_size));
@@ -26,11 +35,12 @@ static size_t levels_ws_need(const m3d_level_t* L, int n_levels, int batch_size,
 extern "C" size_t m3d_levels_workspace_bytes(const m3d_level_t* levels, int n_levels, int batch_size) {
   if (!levels || n_levels < 1) return 256;
   m3d_level_t first = levels[0];
-  // before the counts are known every level is bounded by the first one
+  // before the counts are known every level is bounded by the first one and by its own grid
   size_t need = 256;
   for (int l = 0; l < n_levels; ++l) {
-    need = std::max(need, m3d_strided_rulebook_workspace_bytes(first.n, levels[l].shape, batch_size));
-    need = std::max(need, m3d_subm_rulebook_workspace_bytes(first.n, levels[l].shape, batch_size));
+    const int64_t n = level_bound(levels, l, batch_size);
+    need = std::max(need, m3d_strided_rulebook_workspace_bytes(n, levels[l].shape, batch_size));
+    need = std::max(need, m3d_subm_rulebook_workspace_bytes(n, levels[l].shape, batch_size));
   }
   need = std::max(need, m3d_schedule_workspace_bytes(first.n));
   return need;
@@ -60,10 +70,13 @@ extern "C" int m3d_levels_begin(const m3d_level_t* L, int n_levels, int batch_si
   }
   // the chain of strided maps: the row count of a level stays on the device and feeds the next one
   for (int l = 0; (parts & M3D_LEVELS_CHAIN) && l + 1 < n_levels; ++l) {
-    M3D_CHECK_ARG(L[l].indices && L[l].next_indices && L[l].pair_fwd && L[l].pair_bwd && L[l].ld == L[0].n,
-                  "%s: level %d: strided-map outputs missing or column stride != rows of level 0", who, l);
+    M3D_CHECK_ARG(L[l].indices && L[l].next_indices && L[l].pair_fwd && L[l].pair_bwd, "%s: level %d: strided-map outputs missing",
+                  who, l);
+    M3D_CHECK_ARG(L[l].ld >= level_bound(L, l, batch_size) && L[l].ld <= L[0].n,
+                  "%s: level %d: column stride %lld is not a bound of the level's rows (%lld)", who, l, (long long)L[l].ld,
+                  (long long)level_bound(L, l, batch_size));
     M3D_CHECK_ARG(L[l + 1].indices == L[l].next_indices, "%s: level %d does not read the outputs of level %d", who, l + 1, l);
-    if (int rc = m3d_strided_rulebook(L[l].indices, L[0].n, l ? d_counts + (l - 1) : nullptr, L[l].shape, batch_size,
+    if (int rc = m3d_strided_rulebook(L[l].indices, L[l].ld, l ? d_counts + (l - 1) : nullptr, L[l].shape, batch_size,
                                       L[l].next_indices, L[l].pair_fwd, L[l].pair_bwd, d_counts + l, d_ws, ws_bytes, stream))
       return rc;
   }

@@ -217,7 +217,7 @@ extern "C" int m3d_net_run(const void* net_, const m3d_net_maps_t* maps, const i
         const int64_t rows_in = level_rows[vin.level];
         rc = m3d_conv_fwd_sf32(ptr(L.in0), L.c0, rows_in, ptr(L.in1), L.c1, L.in1 >= 0 ? rows_in : 0, L.weight, L.k, L.cout,
                                s ? s->nbr : nullptr, s ? s->out_row : nullptr, s ? s->tile_mask : nullptr, n,
-                               s ? s->npad : 0, s ? s->tile_order : nullptr, nullptr, nullptr, nullptr, nullptr, L.scale,
+                               s ? s->npad : 0, s ? s->tile_order : nullptr, L.scale,
                                L.shift, res, L.relu, of, L.cout, os, vin.fmt, base + ws_off, ws_bytes, stream);
       }
     } else if (L.op == M3D_NET_SPLIT) {

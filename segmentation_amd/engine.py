@@ -202,9 +202,6 @@ class SpUNetEngine:
         # order below.  With the 128-row tiles launched heaviest first, larger cells (purer patterns, fewer active
         # offsets per tile) beat the spatial locality of small ones: cells of 64 / 32 / all measured 2.8 % slower.
         self.sched_modes = [int(m) for m in os.environ.get("M3D_SCHED_MODES", "2051,3843,3843,0").split(",")]
-        # levels whose submanifold convolutions run on the halo kernel (spatially compact Morton tiles)
-        self.halo_levels = [int(m) for m in os.environ.get("M3D_HALO_LEVELS", "").split(",") if m != ""]
-        self.halo_mode = int(os.environ.get("M3D_HALO_MODE", "1"))
         self._terms = ops.TERMS[precision]
         # with a split precision `final` also writes an sf32 copy of the features for the logits GEMM
         self.head_precision = precision
@@ -315,12 +312,8 @@ class SpUNetEngine:
 
     # ------------------------------------------------------------------ kernel maps
     def _subm_schedule(self, l, pair, n, indices, shape, batch_size):
-        halo = l in self.halo_levels and self._terms == 2
-        mode = self.halo_mode if halo else self.sched_modes[min(l, len(self.sched_modes) - 1)]
-        sched = ops.build_schedule(pair, n, indices, mode, shape, batch_size, tile_order=self.tile_order and not halo)
-        if halo:
-            ops.build_halo(sched, n)
-        return sched
+        mode = self.sched_modes[min(l, len(self.sched_modes) - 1)]
+        return ops.build_schedule(pair, n, indices, mode, shape, batch_size, tile_order=self.tile_order)
 
     def build_levels(self, voxel_coords, spatial_shape, batch_size=1):
         """Kernel maps + tile schedules of every resolution level.  The chain of strided maps runs first, with the
@@ -332,7 +325,7 @@ class SpUNetEngine:
     def build_levels_begin(self, voxel_coords, spatial_shape, batch_size=1):
         """First half of build_levels: enqueues the chain of strided maps and the level-0 map and schedule, and
         returns the function that does the rest (it waits for the level counts, nothing else)."""
-        if self.use_level_chain and not self.halo_levels:
+        if self.use_level_chain:
             # all maps and schedules through two library calls (same bits as the level-by-level calls below)
             modes = [self.sched_modes[min(l, len(self.sched_modes) - 1)] for l in range(self.num_stages + 1)]
             done = ops.level_chain_begin(voxel_coords, spatial_shape, batch_size, self.num_stages, modes, self.tile_order)
@@ -714,7 +707,7 @@ class SpUNetEngine:
         else:
             vox, levels, n_points = maps
         self.last_stats = dict(n_points=n_points, n_voxels=[levels[l].n for l in range(len(levels))])
-        if self.use_plan and not fold_head and not return_features and ops.PROFILE is None and not self.halo_levels \
+        if self.use_plan and not fold_head and not return_features and ops.PROFILE is None \
                 and not (return_logits and self.label_head is not None):
             # the whole network and the head as one library call
             if self._plan is None:

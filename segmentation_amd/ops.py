@@ -207,6 +207,17 @@ def subm_rulebook(indices, spatial_shape, batch_size=0):
 _PINNED_COUNTS = {}
 
 
+def _level_bounds(n0, spatial_shape, batch_size, n_levels):
+    """Upper bound of the rows of every level before the counts are known: the rows of level 0, and the cells of the
+    level's own grid (shape halved per level) when the batch size is known."""
+    shape, out = [int(v) for v in spatial_shape], []
+    for l in range(n_levels):
+        cells = int(batch_size) * shape[0] * shape[1] * shape[2] if batch_size and batch_size > 0 else n0
+        out.append(n0 if l == 0 else max(1, min(n0, cells)))
+        shape = [d // 2 for d in shape]
+    return out
+
+
 def strided_chain(indices, spatial_shape, batch_size, depth, defer=False):
     """`depth` successive k2 s2 p0 kernel maps (v1m3:154-161), each on the previous one's outputs.  The
     output count of a level stays on the device and feeds the next level, so the whole chain is enqueued
@@ -224,13 +235,14 @@ def strided_chain(indices, spatial_shape, batch_size, depth, defer=False):
     dev = indices.device
     counts = torch.empty((depth,), dtype=torch.int64, device=dev)
     bufs, shape, cur = [], [int(s) for s in spatial_shape], indices
+    cap = _level_bounds(n, spatial_shape, batch_size, depth + 1)
     for l in range(depth):
-        out_idx = torch.empty((n, 4), dtype=torch.int32, device=dev)
-        pf = torch.empty((8, n), dtype=torch.int32, device=dev)
-        pb = torch.empty((8, n), dtype=torch.int32, device=dev)
-        ws = _workspace(lib.m3d_strided_rulebook_workspace_bytes(n, _shape3(shape), int(batch_size)), dev)
+        out_idx = torch.empty((cap[l + 1], 4), dtype=torch.int32, device=dev)
+        pf = torch.empty((8, cap[l]), dtype=torch.int32, device=dev)
+        pb = torch.empty((8, cap[l]), dtype=torch.int32, device=dev)
+        ws = _workspace(lib.m3d_strided_rulebook_workspace_bytes(cap[l], _shape3(shape), int(batch_size)), dev)
         d_n_rows = counts[l - 1:l].data_ptr() if l else None
-        rc = lib.m3d_strided_rulebook(_ptr(cur), n, d_n_rows, _shape3(shape), int(batch_size), _ptr(out_idx), _ptr(pf),
+        rc = lib.m3d_strided_rulebook(_ptr(cur), cap[l], d_n_rows, _shape3(shape), int(batch_size), _ptr(out_idx), _ptr(pf),
                                       _ptr(pb), counts[l:l + 1].data_ptr(), _ptr(ws), ws.numel(), _stream())
         _lib.check(rc, "m3d_strided_rulebook")
         shape = [s // 2 for s in shape]
@@ -277,7 +289,6 @@ class Schedule:
     n: int
     npad: int
     k: int
-    halo: object = None      # optional (cnt [npad/256] i32, rows [npad/256, 640] i32, loc [npad/256, k, 256] i16)
     tile_order: object = None  # optional [npad/128] i32: 128-row tiles, heaviest first (m3d_schedule_tile_order)
 
 
@@ -285,11 +296,11 @@ class ArenaSchedule:
     """A Schedule whose arrays are slices of one int32 buffer (the level-chain entry points write all maps and
     schedules of a scene into two such buffers): the device addresses are at hand without creating a tensor per
     array; the tensors are made on request."""
-    __slots__ = ("buf", "o_nbr", "o_row", "o_mask", "o_order", "n", "npad", "k", "halo", "_npairs")
+    __slots__ = ("buf", "o_nbr", "o_row", "o_mask", "o_order", "n", "npad", "k", "_npairs")
 
     def __init__(self, buf, o_nbr, o_row, o_mask, o_order, n, npad, k):
         self.buf, self.o_nbr, self.o_row, self.o_mask, self.o_order = buf, o_nbr, o_row, o_mask, o_order
-        self.n, self.npad, self.k, self.halo, self._npairs = n, npad, k, None, None
+        self.n, self.npad, self.k, self._npairs = n, npad, k, None
 
     def ptr(self, off):
         return None if off < 0 else self.buf.data_ptr() + 4 * off
@@ -357,10 +368,11 @@ def level_chain_begin(indices, spatial_shape, batch_size, depth, subm_modes, til
     if n0 == 0:
         raise ValueError("level_chain needs at least one voxel")
     npad0 = lib.m3d_schedule_npad(n0)
+    cap = _level_bounds(n0, spatial_shape, batch_size, nl)   # rows a level can have before its count is known
     c = _Carver()
-    o_next = [c.take(4 * n0) for _ in range(depth)]
-    o_pf = [c.take(8 * n0) for _ in range(depth)]
-    o_pb = [c.take(8 * n0) for _ in range(depth)]
+    o_next = [c.take(4 * cap[l + 1]) for l in range(depth)]
+    o_pf = [c.take(8 * cap[l]) for l in range(depth)]
+    o_pb = [c.take(8 * cap[l]) for l in range(depth)]
     o_pair0, o_nbr0, o_row0, o_mask0 = c.take(27 * n0), c.take(27 * npad0), c.take(npad0), c.take(npad0 // 32)
     o_ord0 = c.take(npad0 // 128) if tile_order else -1
     buf = torch.empty((c.off,), dtype=torch.int32, device=dev)
@@ -377,7 +389,8 @@ def level_chain_begin(indices, spatial_shape, batch_size, depth, subm_modes, til
         v.shape[0], v.shape[1], v.shape[2] = shape
         v.subm_mode = int(subm_modes[min(l, len(subm_modes) - 1)])
         if l < depth:
-            v.next_indices, v.pair_fwd, v.pair_bwd, v.ld = base + 4 * o_next[l], base + 4 * o_pf[l], base + 4 * o_pb[l], n0
+            v.next_indices, v.pair_fwd, v.pair_bwd = base + 4 * o_next[l], base + 4 * o_pf[l], base + 4 * o_pb[l]
+            v.ld = cap[l]
         shape = [d // 2 for d in shape]
     v = L[0]
     v.pair_subm = base + 4 * o_pair0
@@ -478,8 +491,8 @@ def level_chain_begin(indices, spatial_shape, batch_size, depth, subm_modes, til
                 d["subm"] = ArenaSchedule(buf2, *o_sub[l], n, npad[l], 27)
             if l < depth:
                 m_next = ns[l + 1]
-                d["pair_fwd"] = buf[o_pf[l]:o_pf[l] + 8 * n0].view(8, n0)[:, :m_next]
-                d["pair_bwd"] = buf[o_pb[l]:o_pb[l] + 8 * n0].view(8, n0)[:, :n]
+                d["pair_fwd"] = buf[o_pf[l]:o_pf[l] + 8 * cap[l]].view(8, cap[l])[:, :m_next]
+                d["pair_bwd"] = buf[o_pb[l]:o_pb[l] + 8 * cap[l]].view(8, cap[l])[:, :n]
                 d["next_indices"] = buf[o_next[l]:o_next[l] + 4 * m_next].view(m_next, 4)
                 d["next_shape"], d["n_next"] = shapes[l + 1], m_next
                 d["down"] = ArenaSchedule(buf2, *o_dn[l], -1, m_next, npad[l + 1], 8)
@@ -488,27 +501,6 @@ def level_chain_begin(indices, spatial_shape, batch_size, depth, subm_modes, til
         return out
 
     return finish
-
-
-def build_halo(sched, n_in, order_by_schedule=True):
-    """Attach the halo of every 256-row tile to a schedule (m3d_build_halo): the distinct input rows the tile's
-    pairs reference and, per pair, its index in that list.  conv_fwd then runs the halo kernel for split (sf32,
-    2-term) inputs.  order_by_schedule=True is for submanifold maps (input rows = output rows)."""
-    lib = _lib.load()
-    dev = sched.nbr.device
-    nt = sched.npad // lib.m3d_halo_tile_rows()
-    assert sched.npad % lib.m3d_halo_tile_rows() == 0
-    cnt = torch.empty((nt,), dtype=torch.int32, device=dev)
-    rows = torch.empty((nt, lib.m3d_halo_cap()), dtype=torch.int32, device=dev)
-    loc = torch.empty((nt, sched.k, lib.m3d_halo_tile_rows()), dtype=torch.int16, device=dev)
-    order = torch.empty((nt,), dtype=torch.int32, device=dev)
-    ws = _workspace(max(int(n_in) * 4, 256), dev)
-    rc = lib.m3d_build_halo(_ptr(sched.nbr), _ptr(sched.out_row), sched.k, sched.npad, int(n_in),
-                            int(bool(order_by_schedule)), _ptr(cnt), _ptr(rows), _ptr(loc), _ptr(order), _ptr(ws),
-                            ws.numel(), _stream())
-    _lib.check(rc, "m3d_build_halo")
-    sched.halo = (cnt, rows, loc, order)
-    return sched
 
 
 def build_schedule(pair, n, indices=None, mode=0, spatial_shape=None, batch_size=1, base_order=None,
@@ -736,15 +728,11 @@ def conv_fwd(in0, weight_packed: PackedWeight, sched: Optional[Schedule], n_out,
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
     osp = None if out_sp is None else out_sp.data
-    hcnt = hrows = hloc = horder = None
-    if sf_in and sched is not None and sched.halo is not None and in0.terms == 2:  # the halo kernel is two-term only
-        hcnt, hrows, hloc, horder = sched.halo
     if sf_in:
         rc = lib.m3d_conv_fwd_sf32(_ptr(in0.data), c0, in0.n, _ptr(None if in1 is None else in1.data), c1,
                                    0 if in1 is None else in1.n, _ptr(weight_packed.data), k, cout, _ptr(nbr),
                                    _ptr(orow), _ptr(mask), n_out, npad,
                                    _ptr(None if sched is None else sched.tile_order),
-                                   _ptr(hcnt), _ptr(hrows), _ptr(hloc), _ptr(horder),
                                    _ptr(scale), _ptr(shift), _ptr(residual),
                                    int(bool(relu)), _ptr(out), ldo, _ptr(osp), in0.terms,
                                    _ptr(ws), ws.numel(), _stream())
@@ -758,7 +746,7 @@ def conv_fwd(in0, weight_packed: PackedWeight, sched: Optional[Schedule], n_out,
         _lib.check(rc, "m3d_conv_fwd_f32")
     if prof is not None:
         ev1.record()
-        kind = ("halo" if hcnt is not None else "dma" if sf_in else "igemm") if mfma else "direct"
+        kind = ("dma" if sf_in else "igemm") if mfma else "direct"
         # algorithmic bytes of the launch: activations in and out, the weights and the kernel map, each once
         bpe = 4 if not sf_in else 2 * (2 if in0.terms == FMT_F16_PAIR else in0.terms)
         n_in0 = in0.n if sf_in else in0.shape[0]

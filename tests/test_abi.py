@@ -18,7 +18,7 @@ def _header_symbols():
 def test_header_declares_the_expected_entry_points():
     syms = _header_symbols()
     for name in ("m3d_voxelize", "m3d_subm_rulebook", "m3d_strided_rulebook", "m3d_build_schedule",
-                 "m3d_conv_fwd_f32", "m3d_conv_fwd_sf32", "m3d_build_halo", "m3d_split_f32", "m3d_conv_pack_weight", "m3d_argmax_rows", "m3d_gather_labels",
+                 "m3d_conv_fwd_f32", "m3d_conv_fwd_sf32", "m3d_split_f32", "m3d_conv_pack_weight", "m3d_argmax_rows", "m3d_gather_labels",
                  "m3d_last_error", "m3d_version"):
         assert name in syms
 
@@ -43,7 +43,7 @@ def test_argument_validation_without_gpu():
                               null, 0, 0, null, 0, null)
     assert rc == -1
     rc = lib.m3d_conv_fwd_sf32(one := ctypes.c_void_p(8), 33, 5, null, 0, 0, one, 27, 32, null, null, null, 5, 128, null,
-                               null, null, null, null, null, null, null, 0, one, 32, null, 2, null, 0, null)
+                               null, null, null, 0, one, 32, null, 2, null, 0, null)
     assert rc == -1 and b"multiples of 32" in lib.m3d_last_error()
     assert lib.m3d_schedule_tile_order(one, 100, one, null) == -1 and b"multiple of 128" in lib.m3d_last_error()
     assert lib.m3d_sf32_bytes(10, 64, 2) == 11 * 64 * 4
@@ -52,9 +52,6 @@ def test_argument_validation_without_gpu():
     rc = lib.m3d_subm_rulebook(one, 5, shape, 1, one, null, 0, null)
     assert rc == -1 and b"spatial_shape" in lib.m3d_last_error()
     assert lib.m3d_schedule_npad(1) == 256 and lib.m3d_schedule_npad(257) == 512
-    assert lib.m3d_halo_cap() == 640 and lib.m3d_halo_tile_rows() == 256
-    rc = lib.m3d_build_halo(one, one, 27, 100, 100, 1, one, one, one, one, null, 0, null)
-    assert rc == -1 and b"multiple of 256" in lib.m3d_last_error()
     assert lib.m3d_voxelize_workspace_bytes(1000, 3) > 1000 * 8
     assert lib.m3d_conv_packed_weight_bytes(96, 27, 96, 0) == 96 * 27 * 96 * 4
     assert lib.m3d_conv_packed_weight_bytes(96, 27, 96, 1) == 96 * 27 * 96 * 4

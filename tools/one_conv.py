@@ -1,22 +1,18 @@
-"""One level-0 submanifold 96->96 convolution, for counter collection: python3 tools/one_conv.py halo|dma [reps]."""
+"""One level-0 submanifold 96->96 convolution, for counter collection: python3 tools/one_conv.py [reps]."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from segmentation_amd import ops, scenes
-kind = sys.argv[1] if len(sys.argv) > 1 else "dma"
-reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+kind = "dma"
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 dev = torch.device("cuda:0")
 sc = scenes.make_scene(seed=0, target_voxels=290000)
 n = sc["coord"].shape[0]
 vox = ops.voxelize(torch.from_numpy(sc["coord"]).to(dev), torch.from_numpy(sc["feat"]).to(dev), np.array([0, n]), 0.02)
 idx = vox["voxel_coords"]; N = idx.shape[0]
 pair = ops.subm_rulebook(idx, vox["spatial_shape"])
-mode = int(os.environ.get("SMODE", "1" if kind == "halo" else "1539"))
+mode = int(os.environ.get("SMODE", "1539"))
 sched = ops.build_schedule(pair, N, idx, mode, vox["spatial_shape"], 1)
-if kind == "halo":
-    ops.build_halo(sched, N)
-    c = sched.halo[0].cpu().numpy()
-    print("tiles", len(c), "overflow", int((c < 0).sum()), "mean halo", c[c >= 0].mean(), "max", c.max())
 x = ops.split_f32(torch.randn(N, 96, device=dev), 2)
 w = ops.pack_weight(torch.randn(96, 27, 96) * 0.03, "bf16x3", dev)
 torch.cuda.synchronize()
