@@ -461,7 +461,10 @@ def train_main(args, rank, world, local):
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    under_launcher = all(k in os.environ for k in ("RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"))
+    if world > 1 or (args.force_reducer and under_launcher):
+        # a launcher's rendezvous (its store answers on MASTER_PORT; a tcp:// address of our own would wait for a
+        # server nobody starts)
         import torch.distributed as dist_
         dist = dist_
         dist.init_process_group("nccl", device_id=device)

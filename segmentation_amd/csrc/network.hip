@@ -45,9 +45,16 @@ extern "C" int m3d_net_create(const m3d_net_layer_t* layers, int n_layers, const
                 "%s: bad arguments", who);
   Net* net = new (std::nothrow) Net();
   M3D_CHECK_ARG(net != nullptr, "%s: out of memory", who);
+  try {
+    net->layers.assign(layers, layers + n_layers);
+    net->values.resize(n_values);
+    net->slot_bpr.assign(n_levels, {});
+  } catch (const std::bad_alloc&) {
+    delete net;
+    set_error("%s: out of memory", who);
+    return M3D_EINVAL;
+  }
   net->n_levels = n_levels;
-  net->layers.assign(layers, layers + n_layers);
-  net->values.resize(n_values);
   for (int i = 0; i < n_values; ++i) {
     NetValue& v = net->values[i];
     v.level = values[i].level;
@@ -103,7 +110,6 @@ extern "C" int m3d_net_create(const m3d_net_layer_t* layers, int n_layers, const
   }
   // arena slots: per level, a value takes the first slot that is free when it is written and returns it after its
   // last reader; a slot is as wide as the widest value it ever holds
-  net->slot_bpr.assign(n_levels, {});
   std::vector<std::vector<int>> busy_until(n_levels);
   std::vector<int> order;
   for (int i = 1; i < n_values; ++i)
@@ -233,11 +239,16 @@ extern "C" int m3d_net_run(const void* net_, const m3d_net_maps_t* maps, const i
     } else if (L.op == M3D_NET_ARGMAX) {
       const NetValue& vin = net->values[L.in0];
       M3D_CHECK_ARG(d_voxel_label && vin.fmt == 0, "%s: layer %zu: argmax takes f32 logits and needs d_voxel_label", who, li);
+      M3D_CHECK_ARG(L.n_classes > 0 && L.n_classes <= vin.channels, "%s: layer %zu: %d classes in rows of %d logits", who, li,
+                    L.n_classes, vin.channels);
+      M3D_CHECK_ARG(!d_logits || ldl >= L.n_classes, "%s: logits row stride %lld < %d classes", who, (long long)ldl, L.n_classes);
       rc = m3d_argmax_rows(reinterpret_cast<const float*>(ptr(L.in0)), level_rows[vin.level], L.n_classes, vin.channels,
                            d_voxel_label, stream);
-      if (rc == M3D_OK && d_logits)
-        M3D_HIP(hipMemcpy2DAsync(d_logits, (size_t)ldl * 4, ptr(L.in0), (size_t)vin.channels * 4, (size_t)vin.channels * 4,
+      if (rc == M3D_OK && d_logits) {  // as many columns as the caller's rows hold (the padding columns if there is room)
+        const size_t width = (size_t)std::min<int64_t>(ldl, vin.channels) * 4;
+        M3D_HIP(hipMemcpy2DAsync(d_logits, (size_t)ldl * 4, ptr(L.in0), (size_t)vin.channels * 4, width,
                                  (size_t)level_rows[vin.level], hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream)));
+      }
     } else if (L.op == M3D_NET_GATHER_LABELS) {
       M3D_CHECK_ARG(d_voxel_label && d_v2p_map && d_point_label && n_points > 0, "%s: label gather needs v2p map and outputs", who);
       rc = m3d_gather_labels(d_voxel_label, d_v2p_map, n_points, d_point_label, stream);
