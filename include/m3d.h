@@ -68,6 +68,8 @@ const char* m3d_last_error(void);
  *   d_grid_coord   [n,3] i32   per-point grid coordinate after the min shift (may be NULL)
  *   d_meta         [16]  i64   [0]=n_voxels [1..3]=spatial_shape (max grid + pad)
  *                              [4..6]=grid min before the shift [7..9]=grid max after the shift
+ *                              [12]=1 if that extent + pad reaches 2^31 along an axis (infinite or huge coordinates:
+ *                              the 32-bit grid coordinates have wrapped and the outputs are not to be used), else 0
  */
 size_t m3d_voxelize_workspace_bytes(int64_t n, int c);
 int m3d_voxelize(const float* d_coord, const float* d_feat, const int64_t* d_offset, int64_t n,

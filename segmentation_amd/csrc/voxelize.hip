@@ -175,13 +175,17 @@ __global__ void vox_meta_kernel(const int* __restrict__ mm, const int* __restric
                                 int64_t* __restrict__ meta) {
   if (threadIdx.x != 0) return;
   meta[0] = *d_count;
+  int64_t bad = 0;
   for (int a = 0; a < 3; ++a) {
-    meta[1 + a] = (int64_t)(mm[3 + a] - mm[a]) + pad;
+    const int64_t extent = (int64_t)mm[3 + a] - (int64_t)mm[a];  // in 64 bits: infinite or huge coordinates saturate
+    meta[1 + a] = extent + pad;                                   // the 32-bit grid coordinates at both ends
     meta[4 + a] = mm[a];
-    meta[7 + a] = mm[3 + a] - mm[a];
+    meta[7 + a] = extent;
+    if (extent + pad >= (int64_t)INT_MAX) bad = 1;  // grid coordinates relative to the minimum no longer fit 32 bits
   }
   meta[10] = mm[6];
   meta[11] = mm[7];
+  meta[12] = bad;
 }
 
 struct VoxWs {

@@ -144,6 +144,9 @@ def voxelize(coord, feat, offset, grid_size, pad=128, hash_method="fnv", grid_mo
     _lib.check(rc, "m3d_voxelize")
 
     def result(m):
+        if m[12]:
+            raise ValueError("voxelize: the grid coordinates span 2^31 cells or more along an axis "
+                             f"(extent {[int(v) for v in m[7:10]]}): non-finite or out-of-range point coordinates")
         n0 = m[0]
         out = dict(voxel_coords=voxel_coords[:n0], voxel_feats=voxel_feats[:n0], v2p_map=v2p,
                    spatial_shape=[int(m[1]), int(m[2]), int(m[3])], batch_size=batch_size, n_voxels=n0,

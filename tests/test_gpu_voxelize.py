@@ -219,3 +219,34 @@ def test_reference_pooling_signature_on_the_gpu(golden_voxelize, device, name, h
         compat.gpu_mean_pooling(coords + 1, feat, hash_method=hm)
     with pytest.raises(ValueError):
         compat.gpu_mean_pooling(coords.flip(0), feat, hash_method=hm)
+
+
+@pytest.mark.gpu
+def test_infinite_and_huge_coordinates_are_refused_and_nan_does_no_harm(device):
+    """Coordinates whose grid cells span 2^31 or more along an axis wrap the 32-bit grid coordinates: the voxelizer
+    reports it (meta[12]) and the wrapper raises instead of handing out a wrong grid.  A NaN coordinate converts to
+    cell 0 on this hardware: the call completes and every other point keeps its voxel."""
+    rng = np.random.default_rng(5)
+    n = 4000
+    coord = rng.uniform(0, 3, size=(n, 3)).astype(np.float32)
+    feat = rng.normal(size=(n, 3)).astype(np.float32)
+    good = ops.voxelize(torch.from_numpy(coord).to(device), torch.from_numpy(feat).to(device), [0, n], 0.02)
+    for bad_value in (np.inf, -np.inf, 1e30, -3e38):
+        c2 = coord.copy()
+        c2[17, 1] = bad_value
+        with pytest.raises(ValueError, match="2\\^31"):
+            ops.voxelize(torch.from_numpy(c2).to(device), torch.from_numpy(feat).to(device), [0, n], 0.02)
+        done = ops.voxelize(torch.from_numpy(c2).to(device), torch.from_numpy(feat).to(device), [0, n], 0.02, defer=True)
+        with pytest.raises(ValueError, match="2\\^31"):
+            done()
+    c3 = coord.copy()
+    c3[17, 1] = np.nan
+    out = ops.voxelize(torch.from_numpy(c3).to(device), torch.from_numpy(feat).to(device), [0, n], 0.02)
+    assert abs(out["n_voxels"] - good["n_voxels"]) <= 1
+    keep = np.arange(n) != 17
+    # the other points are grouped exactly as before (voxel ids may shift by the one voxel that changed)
+    a, b = good["v2p_map"].cpu().numpy()[keep], out["v2p_map"].cpu().numpy()[keep]
+    assert len(set(zip(a.tolist(), b.tolist()))) <= max(len(set(a.tolist())), len(set(b.tolist()))) + 1
+    # the library is usable afterwards
+    again = ops.voxelize(torch.from_numpy(coord).to(device), torch.from_numpy(feat).to(device), [0, n], 0.02)
+    assert torch.equal(again["voxel_coords"], good["voxel_coords"]) and torch.equal(again["v2p_map"], good["v2p_map"])
