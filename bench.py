@@ -334,7 +334,7 @@ def main():
                 traffic = json.load(open(pmc))["all_conv_igemm"]["traffic_bytes_per_launch"]
                 break
         peak = PEAK[args.precision]
-        kname = "m3d::conv_igemm_f32_kernel<*>" if args.precision == "f32" else "m3d::conv_igemm_dma_kernel<*>"
+        kname = "m3d::conv_igemm_dma_kernel<*>"
         roofline = dict(bound="mfma", achieved=achieved, peak=peak, unit="TFLOP/s", frac=achieved / peak, traffic=traffic,
                         kernel=kname + " (all tile shapes)", launches_per_step=nl // psteps,
                         flop_per_launch=flops / nl, avg_launch_us=secs / nl * 1e6,

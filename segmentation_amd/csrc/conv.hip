@@ -1,23 +1,23 @@
-// Sparse convolution forward for gfx950: output-stationary implicit GEMM on the exact-f32 matrix
-// instruction v_mfma_f32_32x32x2_f32, with the per-channel affine (folded eval-mode PDBatchNorm),
-// residual add and ReLU fused into the epilogue.
+// Sparse convolution forward for gfx950: output-stationary implicit GEMM on the matrix cores, with the per-channel
+// affine (folded eval-mode PDBatchNorm), residual add and ReLU fused into the epilogue.
 //
 //   out[row(t)] = act(scale * sum_k W[k] . concat(in0, in1)[nbr[k][t]] + shift + residual[row(t)])
 //
 // Work decomposition
 //   * a workgroup owns BM = 32*WM consecutive rows of the tile schedule and BN = 32*NT*WN output
 //     channels; wave (wm, wn) owns 32 rows x 32*NT channels = NT accumulator tiles of 32x32;
-//   * the reduction runs over (active kernel offset k) x (32-channel slab of the input); each
-//     stage gathers BM x 32 input floats (one 128-B line per row) and BN x 32 weights into LDS
-//     (row stride 36 floats: conflict-free ds_read_b128), double-buffered with register
-//     prefetch so that one barrier per stage suffices;
+//   * the reduction runs over (active kernel offset k) x (channel group of the input); each stage moves BM gathered
+//     input rows and BN weight rows of one group into LDS (LDS-DMA kernel: conv_igemm_dma_body; the older
+//     register-staged kernel for in-kernel splits: conv_igemm_split_kernel), double-buffered, one barrier per stage;
+//   * products: exact f32 (v_mfma_f32_32x32x2_f32 on plain f32 rows), or one to three 16-bit terms per operand on
+//     v_mfma_f32_32x32x16_{bf16,f16};
 //   * kernel offsets with no pair in the workgroup's rows are skipped through the 32-row tile
 //     masks; a wave additionally skips the MFMAs of offsets absent from its own 32 rows;
 //   * grid.z > 1 splits the kernel offsets over workgroups for small levels (partial slabs in
 //     the workspace + a fixed-order reduce, so results are run-to-run deterministic).
 //
-// HBM/L2 layout: activations [rows, C] f32 row-major (a gathered row slab is one full 128-B
-// line), weights [k][Cout][Cin] so that a weight slab is also 128 B per output channel.
+// HBM/L2 layout: activations [rows, C] f32 row-major or the split format of conv_shared.h, weights [k][Cout][Cin] f32
+// or [k][Cout][Cin/G][T][G] 16-bit terms.
 #include <mutex>
 #include <type_traits>
 #include "conv_shared.h"
@@ -26,149 +26,6 @@
 
 namespace m3d {
 
-
-template <int WM, int WN, int NT>
-__global__ __launch_bounds__(64 * WM * WN) void conv_igemm_f32_kernel(ConvArgs a) {
-  constexpr int BM = 32 * WM, BN = 32 * NT * WN, NTHR = 64 * WM * WN;
-  constexpr int A_V = (BM * 8 + NTHR - 1) / NTHR;  // float4 per thread, A slab
-  constexpr int W_V = (BN * 8 + NTHR - 1) / NTHR;  // float4 per thread, W slab
-  extern __shared__ __align__(16) float lds[];
-  float* As = lds;                         // [2][BM][kLdr]
-  float* Ws = lds + 2 * BM * kLdr;         // [2][BN][kLdr]
-  int* orow_s = reinterpret_cast<int*>(lds + 2 * (BM + BN) * kLdr);  // [BM]
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave / WN, wn = wave % WN;
-  const int64_t tile_base = (BM == 128 && a.tile_order ? (int64_t)a.tile_order[blockIdx.x] : xcd_tile(blockIdx.x, gridDim.x)) * BM;
-  const int col_base = blockIdx.y * BN;
-  const int cin = a.c0 + a.c1;
-  const int nchunk = cin / kBK;
-
-  uint32_t bmask, wmask;
-  conv_masks<WM>(a, tile_base, wm, bmask, wmask);
-
-  for (int r = tid; r < BM; r += NTHR) {
-    const int64_t t = tile_base + r;
-    orow_s[r] = a.out_row ? a.out_row[t] : (t < a.n ? (int)t : -1);
-  }
-
-  floatx16 acc[NT];
-#pragma unroll
-  for (int i = 0; i < NT; ++i)
-#pragma unroll
-    for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
-
-  const int nk = __popc(bmask);
-  const int nstage = nk * nchunk;
-
-  float4 ra[A_V], rw[W_V];
-  int ridx[A_V];
-
-  // gather row indices of kernel offset k for this thread's A rows
-  auto load_idx = [&](int k) {
-#pragma unroll
-    for (int v = 0; v < A_V; ++v) {
-      const int e = tid + v * NTHR;
-      const int r = e >> 3;
-      int id = -1;
-      if (e < BM * 8) {
-        const int64_t t = tile_base + r;
-        id = a.nbr ? a.nbr[(int64_t)k * a.npad + t] : (t < a.n ? (int)t : -1);
-      }
-      ridx[v] = id;
-    }
-  };
-  auto issue = [&](int k, int cc) {
-    const float* src;
-    int ld, col;
-    if (cc * kBK < a.c0) { src = a.in0; ld = a.c0; col = cc * kBK; }
-    else { src = a.in1; ld = a.c1; col = cc * kBK - a.c0; }
-#pragma unroll
-    for (int v = 0; v < A_V; ++v) {
-      const int e = tid + v * NTHR;
-      const int c4 = e & 7;
-      float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (ridx[v] >= 0)
-        x = *reinterpret_cast<const float4*>(src + (int64_t)ridx[v] * ld + col + c4 * 4);
-      ra[v] = x;
-    }
-#pragma unroll
-    for (int v = 0; v < W_V; ++v) {
-      const int e = tid + v * NTHR;
-      const int j = e >> 3, c4 = e & 7;
-      float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (e < BN * 8)
-        x = *reinterpret_cast<const float4*>(a.weight + ((int64_t)k * a.cout + col_base + j) * cin +
-                                             cc * kBK + c4 * 4);
-      rw[v] = x;
-    }
-  };
-  auto commit = [&](int buf) {
-#pragma unroll
-    for (int v = 0; v < A_V; ++v) {
-      const int e = tid + v * NTHR;
-      if (e < BM * 8)
-        *reinterpret_cast<float4*>(As + (buf * BM + (e >> 3)) * kLdr + (e & 7) * 4) = ra[v];
-    }
-#pragma unroll
-    for (int v = 0; v < W_V; ++v) {
-      const int e = tid + v * NTHR;
-      if (e < BN * 8)
-        *reinterpret_cast<float4*>(Ws + (buf * BN + (e >> 3)) * kLdr + (e & 7) * 4) = rw[v];
-    }
-  };
-
-  if (nstage > 0) {
-    uint32_t rem = bmask;
-    int k = __builtin_ctz(rem);
-    int cc = 0;
-    load_idx(k);
-    issue(k, cc);
-    commit(0);
-    __syncthreads();
-    const int arow = (wm * 32 + (lane & 31)) * kLdr + 4 * (lane >> 5);
-    for (int s = 0; s < nstage; ++s) {
-      const int kcur = k;
-      // advance (k, cc) to the next stage and prefetch it into registers
-      int kn = k, ccn = cc + 1;
-      if (ccn == nchunk) {
-        ccn = 0;
-        rem &= rem - 1;
-        kn = rem ? __builtin_ctz(rem) : k;
-      }
-      const bool more = s + 1 < nstage;
-      if (more) {
-        if (kn != k) load_idx(kn);
-        issue(kn, ccn);
-      }
-      // matrix work on the current buffer
-      if ((wmask >> kcur) & 1u) {
-        const float* Ab = As + (s & 1) * BM * kLdr + arow;
-        const float* Wb = Ws + ((s & 1) * BN + (wn * NT) * 32 + (lane & 31)) * kLdr + 4 * (lane >> 5);
-#pragma unroll
-        for (int g = 0; g < kBK / 8; ++g) {
-          const float4 av = *reinterpret_cast<const float4*>(Ab + g * 8);
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt) {
-            const float4 bv = *reinterpret_cast<const float4*>(Wb + nt * 32 * kLdr + g * 8);
-            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc[nt], 0, 0, 0);
-            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc[nt], 0, 0, 0);
-            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc[nt], 0, 0, 0);
-            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc[nt], 0, 0, 0);
-          }
-        }
-      }
-      if (more) commit((s + 1) & 1);
-      __syncthreads();
-      k = kn;
-      cc = ccn;
-    }
-  } else {
-    __syncthreads();
-  }
-
-  conv_epilogue<NT>(a, acc, orow_s, tile_base, col_base, wm, wn, lane);
-}
 
 // ------------------------------------------------------------------------------------------
 // Split-bf16 variant: every f32 multiplicand is split into T bf16 terms (x = x0 + x1 (+ x2), each
@@ -397,7 +254,8 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvArgs& a) {
   using G = DmaGeom<T>;                                                        // weight image
   // activation image: 16 f32 channels are 64 bytes (T = 3); 32 f32 channels are the 128 bytes of the two-term unit
   using GA = typename std::conditional<AF && T == 3, DmaGeomF32, DmaGeom<T>>::type;
-  static_assert(!AF || T == 3 || T == 2 || T == kFmtF16, "f32 activations: two- and three-term products only");
+  static_assert(!AF || T == 3 || T == 2 || T == kFmtF16 || T == kFmtF32, "f32 activations: split products of two or three terms, or exact f32");
+  static_assert(AF || T != kFmtF32, "exact f32 products take plain f32 rows");
   static_assert(GA::G == G::G && GA::UPS == G::UPS, "activation and weight units cover the same channels");
   constexpr int BM = 32 * WM, BN = 32 * NT * WN, NTHR = 64 * WM * WN;
   constexpr int A_BYTES = BM * GA::ROWB, W_BYTES = BN * G::ROWB, BUF = A_BYTES + W_BYTES;
@@ -635,8 +493,9 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvArgs& a) {
   for (int q = 0; q < NQ; ++q) {
     // f32 rows: the lane's eight consecutive channels of k-step ks are pieces 4 ks + 2h and 4 ks + 2h + 1
     // (T = 3: q = 0, 1, one k-step; T = 2: q = 2 ks + 0, 1)
-    a_off[q] = AF ? arow * GA::ROWB + (((4 * (q >> 1) + 2 * h + (q & 1)) ^ GA::swz(arow)) * 16)
-                  : arow * GA::ROWB + (((2 * q + h) ^ GA::swz(arow)) * 16);
+    // exact f32: no terms to form, the same pieces as the weights (2 q + h)
+    a_off[q] = AF && T != kFmtF32 ? arow * GA::ROWB + (((4 * (q >> 1) + 2 * h + (q & 1)) ^ GA::swz(arow)) * 16)
+                                  : arow * GA::ROWB + (((2 * q + h) ^ GA::swz(arow)) * 16);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       const int j = (wn * NT + nt) * 32 + r32;
@@ -688,6 +547,25 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvArgs& a) {
           acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0], bf[1], acc[1][nt], 0, 0, 0);
           acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[1], bf[0], acc[1][nt], 0, 0, 0);
           acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0], bf[0], acc[0][nt], 0, 0, 0);
+        }
+      }
+    } else if constexpr (T == kFmtF32) {
+      if (!m0) return;
+      // exact f32 products: the lane's four 16-byte pieces hold channels 8 q + 4 h + j (q = piece pair, h = half-wave,
+      // j = 0..3); v_mfma_f32_32x32x2_f32 number (q, j) multiplies the channel pair (8 q + j, 8 q + 4 + j), the two
+      // halves of the wave supplying one channel each, for the activations and the weights alike
+      float4 af[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) af[q] = *reinterpret_cast<const float4*>(buf + a_off[q]);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 bf = *reinterpret_cast<const float4*>(buf + w_off[nt][q]);
+          acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q].x, bf.x, acc[0][nt], 0, 0, 0);
+          acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q].y, bf.y, acc[0][nt], 0, 0, 0);
+          acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q].z, bf.z, acc[0][nt], 0, 0, 0);
+          acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q].w, bf.w, acc[0][nt], 0, 0, 0);
         }
       }
     } else if constexpr (T == 2) {
@@ -1029,18 +907,6 @@ __global__ __launch_bounds__(256) void conv_direct_f32_kernel(ConvArgs a) {
   if (a.out_split) store_split(a.out_split, orow, col, a.cout, a.terms, v, a.f16_status);
 }
 
-template <int WM, int WN, int NT>
-static int launch_igemm(const ConvArgs& a, int nz, hipStream_t stream) {
-  constexpr int BM = 32 * WM, BN = 32 * NT * WN, NTHR = 64 * WM * WN;
-  const size_t lds = (size_t)(2 * (BM + BN) * kLdr) * sizeof(float) + BM * sizeof(int);
-  static LdsGrant grant;
-  if (int rc = grant.ensure(reinterpret_cast<const void*>(&conv_igemm_f32_kernel<WM, WN, NT>), lds)) return rc;
-  dim3 grid((unsigned)(a.npad / BM), (unsigned)(a.cout / BN), (unsigned)nz);
-  hipLaunchKernelGGL((conv_igemm_f32_kernel<WM, WN, NT>), grid, dim3(NTHR), lds, stream, a);
-  M3D_LAUNCH_CHECK();
-  return M3D_OK;
-}
-
 template <int WM, int WN, int NT, int T>
 static int launch_split(const ConvArgs& a, int nz, hipStream_t stream) {
   constexpr int BM = 32 * WM, BN = 32 * NT * WN, NTHR = 64 * WM * WN;
@@ -1176,7 +1042,8 @@ extern "C" size_t m3d_conv_workspace_bytes(int64_t n, int cout, int k) {
   return align_up((size_t)nz * npad * cout * sizeof(float));
 }
 
-// mode: 0 exact f32; 1/2/5 bf16 products with the f32 activations split inside the kernel (T = 2/3/1);
+// mode: 0 exact f32 without the matrix cores (channel counts that are not multiples of 32); 11 exact f32 by LDS-DMA;
+// 1/2/5 bf16 products with the f32 activations split inside the kernel (T = 2/3/1);
 // 3/4/6/9 LDS-DMA on sf32 inputs (T = 2/3/1/f16 pair); 7/8/10 LDS-DMA on f32 inputs, terms formed after the fragment
 // read (T = 3/2/f16 pair)
 static int run_conv(ConvArgs& a, int mode, bool mfma_ok, void* d_ws, size_t ws_bytes, hipStream_t stream,
@@ -1221,8 +1088,7 @@ static int run_conv(ConvArgs& a, int mode, bool mfma_ok, void* d_ws, size_t ws_b
   int rc = M3D_EINVAL;
 #define M3D_CASE(WM_, WN_, NT_)                                                     \
   if (p.wm == WM_ && p.wn == WN_ && p.nt == NT_) {                                  \
-    if (mode == 0) rc = launch_igemm<WM_, WN_, NT_>(a, p.nz, stream);               \
-    else if (mode == 1) rc = launch_split<WM_, WN_, NT_, 2>(a, p.nz, stream);       \
+    if (mode == 1) rc = launch_split<WM_, WN_, NT_, 2>(a, p.nz, stream);       \
     else if (mode == 2) rc = launch_split<WM_, WN_, NT_, 3>(a, p.nz, stream);       \
     else if (mode == 5) rc = launch_split<WM_, WN_, NT_, 1>(a, p.nz, stream);       \
   }
@@ -1235,6 +1101,7 @@ static int run_conv(ConvArgs& a, int mode, bool mfma_ok, void* d_ws, size_t ws_b
     else if (mode == 8) rc = launch_dma_n<WM_, WN_, NT_, 2, 2, true>(a, p.nz, stream); \
     else if (mode == 9) rc = launch_dma_n<WM_, WN_, NT_, kFmtF16, 2, false>(a, p.nz, stream); \
     else if (mode == 10) rc = launch_dma_n<WM_, WN_, NT_, kFmtF16, 2, true>(a, p.nz, stream); \
+    else if (mode == 11) rc = launch_dma_n<WM_, WN_, NT_, kFmtF32, 2, true>(a, p.nz, stream); \
   }
   if (!dma) {
     M3D_CASE(4, 1, 1) M3D_CASE(4, 1, 2) M3D_CASE(4, 1, 3) M3D_CASE(4, 1, 4)
@@ -1318,6 +1185,13 @@ extern "C" int m3d_conv_fwd_f32(const float* d_in0, int c0, const float* d_in1, 
                 "%s: with a bf16 precision both input slabs (%d, %d) must be multiples of 32 channels", who, c0, c1);
   if (int rc = device_symbols(&a.zbuf, &a.f16_status)) return rc;
   int mode = precision == M3D_PREC_BF16 ? 5 : precision;
+  // exact f32 on the matrix cores: rows and weights go to LDS by LDS-DMA with 64-bit addresses (the number of input
+  // rows is not an argument here, so no buffer descriptor can bound them)
+  if (precision == M3D_PREC_F32 && mfma_ok) {
+    mode = 11;
+    a.s0 = reinterpret_cast<const char*>(d_in0);
+    a.s1 = reinterpret_cast<const char*>(d_in1);
+  }
   if (precision == M3D_PREC_F16X3) {
     // the f16 pair has no kernel outside the matrix-core path: small layers (the stem) run in exact f32
     mode = mfma_ok ? 10 : 0;

@@ -48,6 +48,10 @@ typedef _Float16 halfx4 __attribute__((ext_vector_type(4)));
 // apart and scaled back by 2^-11).  An operand is then exact to 2^-22 of its value, and a value beyond the f16
 // range (65504) raises the library's f16 status word instead of going unnoticed.
 constexpr int kFmtF16 = 4;
+// Kernel-internal code of the LDS-DMA convolution (never a storage format of a caller): both operands are plain f32
+// rows, 32 channels = 128 bytes per unit -- the geometry of two 16-bit terms -- and the products are exact f32
+// (v_mfma_f32_32x32x2_f32).
+constexpr int kFmtF32 = 5;
 constexpr float kF16Scale = 2048.f, kF16Unscale = 1.f / 2048.f, kF16Max = 65504.f;
 __host__ __device__ inline int split_nterms(int fmt) { return fmt == kFmtF16 ? 2 : fmt; }
 __host__ __device__ inline int split_group_shift(int terms) { return terms == 3 ? 4 : 5; }
@@ -298,7 +302,7 @@ constexpr int kLdr = 36;  // LDS row stride in floats
 // whose rows cover every residue mod 16; with 128-byte rows two rows share a 256-byte bank line and the eight
 // row pairs take the eight XOR patterns; with 96-byte rows the rows r and r + 8 start on the same banks and take
 // the two slots of a piece pair.
-// T = kFmtF16 (the f16 pair) has the geometry of T = 2.
+// T = kFmtF16 (the f16 pair) and T = kFmtF32 (plain f32 rows, 32 channels per unit) have the geometry of T = 2.
 template <int T>
 struct DmaGeom {
   static constexpr int G = T == 3 ? 16 : 32;   // channels per unit
