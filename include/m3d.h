@@ -230,12 +230,15 @@ int m3d_schedule_tile_order(const uint32_t* d_tile_mask, int64_t npad, int32_t* 
  *   d_scale/d_shift [cout] may be NULL (1 / 0); d_residual [n_out_rows,cout] may be NULL
  *   d_out [n_out_rows, ldo] (ldo >= cout, row stride in floats)
  *   n = number of real output rows; npad = schedule length
- * With M3D_PREC_BF16X3 / M3D_PREC_BF16X6 and channel counts that are multiples of 32 the f32 rows are gathered into
- * LDS as they are and split into bf16 terms after the fragment read: the same terms, products and summation order
- * as m3d_conv_fwd_sf32 on a tensor split beforehand, so the two entry points agree bit for bit.
+ * With M3D_PREC_BF16X3 / M3D_PREC_BF16X6 / M3D_PREC_F16X3 and channel counts that are multiples of 32 the f32 rows are
+ * gathered into LDS as they are and split into 16-bit terms after the fragment read: the same terms, products and
+ * summation order as m3d_conv_fwd_sf32 on a tensor split beforehand, so the two entry points agree bit for bit.  The
+ * requests are buffer loads with 32-bit offsets, as there: rows0 / rows1 (the rows d_in0 / d_in1 hold; every index of
+ * the kernel map lies below them) are required and every operand must stay below 4 GB, else M3D_EINVAL.  The other
+ * precisions ignore rows0 / rows1 (0 is allowed).
  */
 size_t m3d_conv_workspace_bytes(int64_t n, int cout, int k);
-int m3d_conv_fwd_f32(const float* d_in0, int c0, const float* d_in1, int c1,
+int m3d_conv_fwd_f32(const float* d_in0, int c0, int64_t rows0, const float* d_in1, int c1, int64_t rows1,
                      const float* d_weight, int k, int cout, const int32_t* d_nbr,
                      const int32_t* d_out_row, const uint32_t* d_tile_mask, int64_t n,
                      int64_t npad, const int32_t* d_tile_order, const float* d_scale, const float* d_shift,

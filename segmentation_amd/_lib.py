@@ -41,7 +41,7 @@ SIGNATURES = {
     "m3d_build_schedule": (_int, [_vp, _int, _i64, _i64, _vp, ctypes.POINTER(_i64), _int, _int, _vp,
                                   _vp, _vp, _vp, _vp, _sz, _vp]),
     "m3d_conv_workspace_bytes": (_sz, [_i64, _int, _int]),
-    "m3d_conv_fwd_f32": (_int, [_vp, _int, _vp, _int, _vp, _int, _int, _vp, _vp, _vp, _i64, _i64, _vp,
+    "m3d_conv_fwd_f32": (_int, [_vp, _int, _i64, _vp, _int, _i64, _vp, _int, _int, _vp, _vp, _vp, _i64, _i64, _vp,
                                 _vp, _vp, _vp, _int, _vp, _i64, _vp, _int, _int, _vp, _sz, _vp]),
     "m3d_schedule_tile_order": (_int, [_vp, _i64, _vp, _vp]),
     "m3d_conv_fwd_sf32": (_int, [_vp, _int, _i64, _vp, _int, _i64, _vp, _int, _int, _vp, _vp, _vp, _i64, _i64, _vp,

@@ -290,7 +290,7 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvArgs& a) {
   // spends no vector instruction on addresses (with 64-bit per-lane addresses it spent three per request, and the
   // request itself cost its wave more).  A missing neighbour gets an offset beyond the buffer's size: the hardware
   // then writes zeros to LDS without a memory request.  Operands are limited to kDmaBufferBytes (checked by the host).
-  constexpr bool BUFA = !AF && UPS == 1;
+  constexpr bool BUFA = UPS == 1 && T != kFmtF32;
   static_assert(!GMAP || (BUFA && BM == 128 && NBUF == 2), "kernel map in global memory: 128-row tiles of the buffer-addressed path");
   constexpr int kRsrcWord3 = 0x00020000;  // raw buffer, 32-bit elements
   const __amdgpu_buffer_rsrc_t rs0 =
@@ -990,6 +990,15 @@ static int launch_dma(const ConvArgs& a, int nz, hipStream_t stream) {
   return launch_dma_n<WM, WN, NT, T, 2>(a, nz, stream);
 }
 
+template <int WM, int WN, int NT>
+static int launch_af3(const ConvArgs& a, int nz, hipStream_t stream) {
+  if constexpr (WM == 4 && WN == 1 && NT == 3) {
+    static const int64_t gmap_tiles = getenv("M3D_GMAP_TILES") ? atoll(getenv("M3D_GMAP_TILES")) : 1024;
+    if (a.nbr && nz == 1 && a.npad / 128 >= gmap_tiles) return launch_dma_n<WM, WN, NT, 3, 2, true, true>(a, nz, stream);
+  }
+  return launch_dma_n<WM, WN, NT, 3, 2, true>(a, nz, stream);
+}
+
 // Tile configuration.  Column tile: the widest of 128/96/64/32 dividing cout.  Row tile and offset split:
 // short reductions (fewer than three 32-channel slabs per offset) start from 64-row tiles, longer ones from
 // 128-row tiles (the weight stream is amortised over more rows); the kernel offsets are split nz ways until
@@ -1043,7 +1052,7 @@ extern "C" size_t m3d_conv_workspace_bytes(int64_t n, int cout, int k) {
 }
 
 // mode: 0 exact f32 without the matrix cores (channel counts that are not multiples of 32); 11 exact f32 by LDS-DMA;
-// 1/2/5 bf16 products with the f32 activations split inside the kernel (T = 2/3/1);
+// 5 plain bf16 products with the f32 activations rounded on their way to LDS;
 // 3/4/6/9 LDS-DMA on sf32 inputs (T = 2/3/1/f16 pair); 7/8/10 LDS-DMA on f32 inputs, terms formed after the fragment
 // read (T = 3/2/f16 pair)
 static int run_conv(ConvArgs& a, int mode, bool mfma_ok, void* d_ws, size_t ws_bytes, hipStream_t stream,
@@ -1088,16 +1097,14 @@ static int run_conv(ConvArgs& a, int mode, bool mfma_ok, void* d_ws, size_t ws_b
   int rc = M3D_EINVAL;
 #define M3D_CASE(WM_, WN_, NT_)                                                     \
   if (p.wm == WM_ && p.wn == WN_ && p.nt == NT_) {                                  \
-    if (mode == 1) rc = launch_split<WM_, WN_, NT_, 2>(a, p.nz, stream);       \
-    else if (mode == 2) rc = launch_split<WM_, WN_, NT_, 3>(a, p.nz, stream);       \
-    else if (mode == 5) rc = launch_split<WM_, WN_, NT_, 1>(a, p.nz, stream);       \
+    if (mode == 5) rc = launch_split<WM_, WN_, NT_, 1>(a, p.nz, stream);            \
   }
 #define M3D_CASE_DMA(WM_, WN_, NT_)                                                 \
   if (p.wm == WM_ && p.wn == WN_ && p.nt == NT_) {                                  \
     if (mode == 3) rc = launch_dma<WM_, WN_, NT_, 2>(a, p.nz, stream);              \
     else if (mode == 4) rc = launch_dma<WM_, WN_, NT_, 3>(a, p.nz, stream);         \
     else if (mode == 6) rc = launch_dma<WM_, WN_, NT_, 1>(a, p.nz, stream);         \
-    else if (mode == 7) rc = launch_dma_n<WM_, WN_, NT_, 3, 2, true>(a, p.nz, stream); \
+    else if (mode == 7) rc = launch_af3<WM_, WN_, NT_>(a, p.nz, stream); \
     else if (mode == 8) rc = launch_dma_n<WM_, WN_, NT_, 2, 2, true>(a, p.nz, stream); \
     else if (mode == 9) rc = launch_dma_n<WM_, WN_, NT_, kFmtF16, 2, false>(a, p.nz, stream); \
     else if (mode == 10) rc = launch_dma_n<WM_, WN_, NT_, kFmtF16, 2, true>(a, p.nz, stream); \
@@ -1152,7 +1159,7 @@ static int check_schedule(const int32_t* d_nbr, const int32_t* d_out_row, const 
   return M3D_OK;
 }
 
-extern "C" int m3d_conv_fwd_f32(const float* d_in0, int c0, const float* d_in1, int c1,
+extern "C" int m3d_conv_fwd_f32(const float* d_in0, int c0, int64_t rows0, const float* d_in1, int c1, int64_t rows1,
                                 const float* d_weight, int k, int cout, const int32_t* d_nbr,
                                 const int32_t* d_out_row, const uint32_t* d_tile_mask, int64_t n,
                                 int64_t npad, const int32_t* d_tile_order, const float* d_scale, const float* d_shift,
@@ -1198,15 +1205,20 @@ extern "C" int m3d_conv_fwd_f32(const float* d_in0, int c0, const float* d_in1, 
     a.s0 = reinterpret_cast<const char*>(d_in0);
     a.s1 = reinterpret_cast<const char*>(d_in1);
   }
-  // split products: the f32 rows go to LDS as they are (M3D_F32_DMA=0: split in registers on the way to LDS)
-  static const bool f32_dma = [] {
-    const char* e = getenv("M3D_F32_DMA");
-    return !(e && e[0] == '0');
-  }();
-  if ((mode == 1 || mode == 2) && mfma_ok && f32_dma) {
+  // split products: the f32 rows go to LDS as they are and the terms are formed after the fragment read
+  if ((mode == 1 || mode == 2) && mfma_ok) {
     mode = mode == 2 ? 7 : 8;
     a.s0 = reinterpret_cast<const char*>(d_in0);
     a.s1 = reinterpret_cast<const char*>(d_in1);
+  }
+  if (mode == 7 || mode == 8 || mode == 10) {
+    // the kernel addresses every operand with 32-bit byte offsets inside one buffer descriptor
+    M3D_CHECK_ARG(rows0 > 0 && (d_in1 == nullptr || rows1 > 0), "%s: rows0 / rows1 are required at this precision", who);
+    M3D_CHECK_ARG(d_nbr != nullptr || rows0 >= n, "%s: dense mode needs rows0 >= n", who);
+    const int64_t cmax = c0 > c1 ? c0 : c1, rmax = rows0 > rows1 ? rows0 : rows1;
+    M3D_CHECK_ARG(rmax * cmax * 4 <= (int64_t)kDmaBufferBytes && (int64_t)k * cout * (c0 + c1) * 6 <= (int64_t)kDmaBufferBytes,
+                  "%s: an operand of more than 4 GB (%lld rows x %lld channels) is beyond the kernel's buffer addressing",
+                  who, (long long)rmax, (long long)cmax);
   }
   return run_conv(a, mode, mfma_ok, d_ws, ws_bytes, stream, who);
 }

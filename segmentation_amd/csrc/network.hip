@@ -214,8 +214,9 @@ extern "C" int m3d_net_run(const void* net_, const m3d_net_maps_t* maps, const i
       void* os = ptr(L.out_split);
       const int oterms = L.out_split >= 0 ? net->values[L.out_split].fmt : 0;
       if (vin.fmt == 0) {
-        rc = m3d_conv_fwd_f32(reinterpret_cast<const float*>(ptr(L.in0)), L.c0, reinterpret_cast<const float*>(ptr(L.in1)),
-                              L.c1, static_cast<const float*>(L.weight), L.k, L.cout, s ? s->nbr : nullptr,
+        const int64_t rows_in = level_rows[vin.level];
+        rc = m3d_conv_fwd_f32(reinterpret_cast<const float*>(ptr(L.in0)), L.c0, rows_in, reinterpret_cast<const float*>(ptr(L.in1)),
+                              L.c1, L.in1 >= 0 ? rows_in : 0, static_cast<const float*>(L.weight), L.k, L.cout, s ? s->nbr : nullptr,
                               s ? s->out_row : nullptr, s ? s->tile_mask : nullptr, n, s ? s->npad : 0,
                               s ? s->tile_order : nullptr, L.scale, L.shift, res, L.relu, of, L.cout, os, oterms, L.precision,
                               base + ws_off, ws_bytes, stream);

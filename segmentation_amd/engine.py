@@ -203,6 +203,15 @@ class SpUNetEngine:
         # offsets per tile) beat the spatial locality of small ones: cells of 64 / 32 / all measured 2.8 % slower.
         self.sched_modes = [int(m) for m in os.environ.get("M3D_SCHED_MODES", "2051,3843,3843,0").split(",")]
         self._terms = ops.TERMS[precision]
+        # levels whose activations travel as plain f32 rows only: the convolutions gather the f32 rows and form the
+        # terms after the fragment read -- the same terms, products and bits as on rows split beforehand.  With three
+        # terms a level-0 tensor is then written once at 4 bytes per element instead of 6 (+ 4 where a residual needs
+        # the f32 copy as well) and gathered at 4: the 30-scene sequence 5.25 -> 5.09 ms per scene with level 0 alone,
+        # the same with level 1 added, slower from level 2 on.  With two terms the split rows are 4 bytes per element
+        # already and the plain rows only add the forming of the terms (f16x3 3.38 -> 3.62 ms): off.
+        default = "0" if self._terms == 3 else ""
+        self.act_f32 = set(int(v) for v in os.environ.get("M3D_ACT_F32_LEVELS", default).split(",") if v != "") \
+            if self._terms in (2, 3, 4) else set()
         # with a split precision `final` also writes an sf32 copy of the features for the logits GEMM
         self.head_precision = precision
         self.fuse_head = os.environ.get("M3D_FUSE_HEAD", "1") != "0"
@@ -390,9 +399,9 @@ class SpUNetEngine:
         if x[1] is not None and c.w.precision != "f32":
             r = ops.conv_fwd(x[1], c.w, sched, n, in1=None if x2 is None else x2[1], scale=c.scale, shift=c.shift,
                              residual=residual, relu=relu, want_f32=need_f32, split_terms=T if need_sf else 0)
-        else:  # f32 input (the 3-channel stem runs on the direct kernel)
-            r = ops.conv_fwd(x[0], c.w, sched, n, scale=c.scale, shift=c.shift, residual=residual, relu=relu,
-                             want_f32=need_f32, split_terms=T if need_sf else 0)
+        else:  # f32 input (the 3-channel stem runs on the direct kernel; levels kept as plain f32 rows)
+            r = ops.conv_fwd(x[0], c.w, sched, n, in1=None if x2 is None else x2[0], scale=c.scale, shift=c.shift,
+                             residual=residual, relu=relu, want_f32=need_f32, split_terms=T if need_sf else 0)
         return r if need_sf else (r, None)
 
     def _conv_traced(self, c, x, sched, x2, residual, relu, need_f32, need_sf):
@@ -403,7 +412,7 @@ class SpUNetEngine:
         elif x[1] is not None and c.w.precision != "f32":
             in0, in1, want_f32, split = x[1], None if x2 is None else x2[1], need_f32, (T if need_sf else 0)
         else:
-            in0, in1, want_f32, split = x[0], None, need_f32, (T if need_sf else 0)
+            in0, in1, want_f32, split = x[0], None if x2 is None else x2[0], need_f32, (T if need_sf else 0)
         level = tr.values[in0][0] if sched is None else sched[1]
         out_f32 = tr.new(level, c.cout, 0) if want_f32 else None
         out_sf = tr.new(level, c.cout, split) if split else None
@@ -443,15 +452,16 @@ class SpUNetEngine:
             self._trace = None
         return _NetPlan(tr, nl, cpad)
 
-    def _block(self, blk, x, sched, n, x2=None, last_needs_f32=True):
-        """BasicBlock with fused epilogues; (x, x2) are the two K-slabs of a concatenated input."""
+    def _block(self, blk, x, sched, n, x2=None, last_needs_f32=True, plain=False, last_needs_sf=True):
+        """BasicBlock with fused epilogues; (x, x2) are the two K-slabs of a concatenated input.  plain: the level's
+        activations are f32 rows only (last_needs_sf: the block's output is wanted in the split format all the same)."""
         if "proj" in blk:
             res = self._conv(blk["proj"], x, None, n, x2=x2, need_f32=True, need_sf=False)[0]
         else:
             res = x[0]
-        t = self._conv(blk["conv1"], x, sched, n, x2=x2, relu=True, need_f32=self._terms == 0)
+        t = self._conv(blk["conv1"], x, sched, n, x2=x2, relu=True, need_f32=self._terms == 0 or plain, need_sf=not plain)
         return self._conv(blk["conv2"], t, sched, n, residual=res, relu=True,
-                          need_f32=last_needs_f32 or self._terms == 0)
+                          need_f32=last_needs_f32 or self._terms == 0, need_sf=last_needs_sf or not plain)
 
     def backbone(self, voxel_feats, levels, keep=None, last_f32=False):
         """SpUNetBase.forward after sparsify (v1m3:388-407).  Returns the activation pair of the last decoder
@@ -459,30 +469,35 @@ class SpUNetEngine:
         ns = self.num_stages
         l0 = levels[0]
         f32_only = self._terms == 0
-        x = self._conv(self.stem, (voxel_feats, None), l0.subm, l0.n, relu=True, need_f32=f32_only or keep is not None)
+        plain = [l in self.act_f32 for l in range(ns + 1)]
+        x = self._conv(self.stem, (voxel_feats, None), l0.subm, l0.n, relu=True,
+                       need_f32=f32_only or keep is not None or plain[0], need_sf=not plain[0])
         if keep is not None:
             keep["conv_input"] = x[0]
         skips = [x]
         for s in range(ns):
-            x = self._conv(self.down[s], x, levels[s].down, levels[s].n_next, relu=True, need_f32=True)
+            x = self._conv(self.down[s], x, levels[s].down, levels[s].n_next, relu=True, need_f32=True,
+                           need_sf=not plain[s + 1])
             if keep is not None:
                 keep[f"down.{s}"] = x[0]
             for blk in self.enc[s]:
-                x = self._block(blk, x, levels[s + 1].subm, levels[s + 1].n)
+                x = self._block(blk, x, levels[s + 1].subm, levels[s + 1].n, plain=plain[s + 1], last_needs_sf=False)
             if keep is not None:
                 keep[f"enc.{s}"] = x[0]
             skips.append(x)
         x = skips.pop(-1)
         for s in reversed(range(ns)):
-            x = self._conv(self.up[s], x, levels[s].up, levels[s].n, relu=True, need_f32=f32_only or keep is not None)
+            x = self._conv(self.up[s], x, levels[s].up, levels[s].n, relu=True,
+                           need_f32=f32_only or keep is not None or plain[s], need_sf=not plain[s])
             if keep is not None:
                 keep[f"up.{s}"] = x[0]
             skip = skips.pop(-1)
             for i, blk in enumerate(self.dec[s]):
                 # the network's last block feeds `final` / the head, which read the split copy only
                 last = s == 0 and i == len(self.dec[s]) - 1 and keep is None
+                # (its output in the split format also where the level's activations are plain f32 rows)
                 x = self._block(blk, x, levels[s].subm, levels[s].n, x2=skip if i == 0 else None,
-                                last_needs_f32=last_f32 or not last)
+                                last_needs_f32=last_f32 or not last, plain=plain[s], last_needs_sf=last)
             if keep is not None:
                 keep[f"dec.{s}"] = x[0]
         return x

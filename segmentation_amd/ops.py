@@ -741,7 +741,8 @@ def conv_fwd(in0, weight_packed: PackedWeight, sched: Optional[Schedule], n_out,
                                    _ptr(ws), ws.numel(), _stream())
         _lib.check(rc, "m3d_conv_fwd_sf32")
     else:
-        rc = lib.m3d_conv_fwd_f32(_ptr(in0), c0, _ptr(in1), c1, _ptr(weight_packed.data), k, cout, _ptr(nbr),
+        rc = lib.m3d_conv_fwd_f32(_ptr(in0), c0, in0.shape[0], _ptr(in1), c1, 0 if in1 is None else in1.shape[0],
+                                  _ptr(weight_packed.data), k, cout, _ptr(nbr),
                                   _ptr(orow), _ptr(mask), n_out, npad,
                                   _ptr(None if sched is None else sched.tile_order), _ptr(scale), _ptr(shift),
                                   _ptr(residual), int(bool(relu)), _ptr(out), ldo, _ptr(osp), split_terms,

@@ -39,7 +39,7 @@ def test_argument_validation_without_gpu():
     null = ctypes.c_void_p(0)
     rc = lib.m3d_voxelize(null, null, null, 10, 3, 1, 0.02, 128, 0, 0, null, null, null, null, null, null, null, 0, null)
     assert rc == -1 and b"null pointer" in lib.m3d_last_error()
-    rc = lib.m3d_conv_fwd_f32(null, 32, null, 0, null, 27, 32, null, null, null, 5, 128, null, null, null, null, 0, null, 32,
+    rc = lib.m3d_conv_fwd_f32(null, 32, 5, null, 0, 0, null, 27, 32, null, null, null, 5, 128, null, null, null, null, 0, null, 32,
                               null, 0, 0, null, 0, null)
     assert rc == -1
     rc = lib.m3d_conv_fwd_sf32(one := ctypes.c_void_p(8), 33, 5, null, 0, 0, one, 27, 32, null, null, null, 5, 128, null,

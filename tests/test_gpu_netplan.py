@@ -86,3 +86,29 @@ def test_network_description_is_checked():
         arr = (_lib.NetLayer * 1)(bad)
         assert lib.m3d_net_create(arr, 1, vals, 3, 2, ctypes.byref(h)) == -1
         assert msg in lib.m3d_last_error(), (msg, lib.m3d_last_error())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec", ["bf16x6", "bf16x3", "f16x3"])
+def test_plain_f32_activation_levels_give_the_same_bits(device, prec, monkeypatch):
+    """Levels whose activations travel as plain f32 rows (the default for level 0 at three terms) against the engine
+    that keeps every level in the split format: the convolutions form the same terms after the fragment read, so
+    features, logits and labels are the same bits, through the plan and layer by layer."""
+    sc = _scene(98, 30000, device)
+    outs = {}
+    for levels in ("", "0", "0,1", "0,1,2,3,4"):
+        monkeypatch.setenv("M3D_ACT_F32_LEVELS", levels)
+        eng, _, _ = bench.build_engine(device, prec)
+        assert eng.act_f32 == {int(v) for v in levels.split(",") if v}
+        with torch.no_grad():
+            o = eng.predict(*sc, return_logits=True)
+            eng.use_plan = False
+            o2 = eng.predict(*sc, return_logits=True)
+            f, _ = eng.forward_features(*sc)
+        assert torch.equal(o["pred"], o2["pred"]) and torch.equal(o["voxel_logits"], o2["voxel_logits"])
+        outs[levels] = (o["pred"], o["voxel_logits"], f)
+    for levels, (p, l, f) in outs.items():
+        assert torch.equal(p, outs[""][0]) and torch.equal(l, outs[""][1]) and torch.equal(f, outs[""][2]), levels
+    monkeypatch.delenv("M3D_ACT_F32_LEVELS")
+    assert bench.build_engine(device, "bf16x6")[0].act_f32 == {0}
+    assert bench.build_engine(device, "f16x3")[0].act_f32 == set()
